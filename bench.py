@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""bench.py -- coordinate updates per second of the full cyclic Lasso sweep.
+
+One "step" = one full cyclic pass (`_cdPass!` over 1..p, src/coordinate_descent.jl:
+94-110) = p coordinate updates on BASELINE.json's config: Lasso, dense Gaussian X,
+n = 10,000,000, p = 1,000, fp64, generated in HBM (synthetic).  lambda = 1e-3 *
+lambda_max so every coordinate moves (h != 0) on every visit ("all-move", SURVEY.md
+section 8d) -- the most expensive regime: every visit pays the residual update.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME 10M x 1000
+problem with rows sharded across ranks (strong scaling), gradient scalars summed by an
+RCCL all-reduce inside the library.
+
+Prints ONE JSON line on rank 0.  `roofline` is computed from HIP events recorded on the
+library's own stream around the sweep kernels; `cpu_baseline` times the CPU oracle's
+restatement of the reference visit (kind "port": the reference is Julia, not runnable
+here) on a bounded sample of the same data.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(f, n, lam, visits_target_s=12.0):
+    """CPU oracle (port of cd_differentiable_function.jl:96-99,107-109) on a 32-column
+    slice of the same X, single thread (faithful: the reference has no threading) and
+    all host cores (OpenMP over n: a ceiling the reference does not have)."""
+    import ctypes as C
+    import numpy as np
+    import oracle as O
+    L = O.lib()
+    ncol = 32
+    X = f.X_cols(0, ncol)            # the device-generated data itself
+    y = f.y
+    out = {}
+    for threads in (1, int(L.cdo_max_threads())):
+        r = y.copy()
+        beta = np.zeros(ncol)
+        # calibrate on one cycle over the slice, then size the sample to ~visits_target_s
+        t0 = time.perf_counter()
+        L.cdo_bench_ls_visits(n, ncol, O._ptr(X), n, O._ptr(r), O._ptr(beta), lam, ncol, threads)
+        per = (time.perf_counter() - t0) / ncol
+        visits = int(max(ncol, min(4096, visits_target_s / per)) // ncol * ncol)
+        t0 = time.perf_counter()
+        L.cdo_bench_ls_visits(n, ncol, O._ptr(X), n, O._ptr(r), O._ptr(beta), lam, visits, threads)
+        dt = time.perf_counter() - t0
+        out[threads] = dict(value=visits / dt, unit="coord-updates/s", cores=threads, kind="port",
+                            sample=f"{visits} visits cycling a {ncol}-column slice of the same X, n={n}, fp64; "
+                                   f"{dt / visits * 1e3:.2f} ms/visit; p-sweep extrapolated x(p/visits)")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--p", type=int, default=1000)
+    ap.add_argument("--s", type=int, default=100)
+    ap.add_argument("--noise", type=float, default=6.0)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--mode", default=os.environ.get("CDH_BENCH_MODE", "block"), choices=["coord", "block"])
+    ap.add_argument("--block", type=int, default=8)
+    ap.add_argument("--lam-frac", type=float, default=1e-3, help="lambda / lambda_max")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import coordinatedescent_jl_amd as cd
+    from importlib import import_module
+    sharded = import_module("coordinatedescent_jl_amd.sharded")
+
+    cp = sharded.ControlPlane()
+    assert cp.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={cp.world}"
+    row0, n_local = sharded.shard_rows(a.n, cp.rank, cp.world)
+    dtype = np.float64 if a.dtype == "f64" else np.float32
+    L = cd._lib.lib()
+    ndev = cd._lib.C.c_int32()
+    L.cdh_device_count(cd._lib.C.byref(ndev))
+    device = cp.local_rank % max(ndev.value, 1)
+
+    f, bstar = cd.CDLeastSquaresLoss.generate(n_local, a.p, seed=123, s=a.s, noise=a.noise, dtype=dtype,
+                                              device=device, n_total=a.n, row_offset=row0)
+    sharded.connect(f, cp)
+    f.set_sweep_mode(a.mode, a.block)
+    x = cd.SparseIterate(a.p)
+    cd.initialize_(f, x)
+    lmax = cd.findLambdaMax(x, f, cd.ProxL1(1.0))
+    g = cd.ProxL1(a.lam_frac * lmax)
+    visit = list(range(1, a.p + 1))
+
+    for _ in range(a.warmup):
+        cd.cdPass_(x, f, g, visit)
+    cp.barrier()
+    L.cdh_synchronize(f._h)
+    f.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        maxh = cd.cdPass_(x, f, g, visit)
+    L.cdh_synchronize(f._h)
+    cp.barrier()
+    dt = cp.max_over_ranks(time.perf_counter() - t0)
+    ev_ms, launches, alg_bytes = f.profile_end()
+
+    updates = a.steps * a.p
+    value = updates / dt
+    esz = np.dtype(dtype).itemsize
+    # roofline of the dominant (column-streaming) kernel, per launch, this rank's shard
+    achieved = alg_bytes / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else 0.0
+    stream_model = esz * n_local * 5.0 * updates / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else 0.0
+    kernel = "k_blockstep" if a.mode == "block" else "k_step"
+    res = {
+        "metric": "coord_updates_per_sec", "value": value, "unit": "coord-updates/s",
+        "n_gpus": cp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype,
+        "data": "synthetic",
+        "config": {"workload": f"lasso_full_cyclic_sweep_gaussian_n{a.n}_p{a.p}_{a.dtype}_allmove",
+                   "n": a.n, "p": a.p, "s": a.s, "noise": a.noise, "lambda_over_lambda_max": a.lam_frac,
+                   "sweep_mode": a.mode + (str(a.block) if a.mode == "block" else ""),
+                   "parallelism": f"rows{cp.world}", "nnz_after": int(x.nnz), "last_maxH": maxh},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+                     "launches": launches, "avg_launch_us": ev_ms * 1e3 / max(launches, 1),
+                     "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
+                     "stream_model_5n_GBps": stream_model,
+                     "floor_X_once_GBps": esz * n_local * updates / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else 0.0},
+    }
+    if cp.rank == 0 and cp.world == 1 and not a.no_cpu_baseline:
+        cb = cpu_baseline(f, n_local, g.lambda0)
+        res["cpu_baseline"] = cb[1]
+        mt = [v for k, v in cb.items() if k != 1]
+        if mt:
+            res["cpu_baseline_all_cores"] = mt[0]
+    if cp.rank == 0:
+        print(json.dumps(res), flush=True)
+    f.close()
+    cp.shutdown()
+
+
+if __name__ == "__main__":
+    main()

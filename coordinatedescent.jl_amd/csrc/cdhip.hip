@@ -1,0 +1,865 @@
+// cdhip.hip -- the C-ABI library (include/cdhip.h): handle, device memory, the pass
+// / solve state machine of src/coordinate_descent.jl restated on the host, launches
+// of the kernels in kernels.hpp, RCCL row-shard all-reduce.  gfx950 only.
+#include "../../include/cdhip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "sparse_iterate.hpp"
+
+using namespace cdk;
+
+namespace {
+
+std::string g_create_error;
+
+constexpr int kMaxStepGrid = 2048;   // blocks of k_step (8 per CU on 256 CUs)
+constexpr int kBlockGridPerCU = 3;   // k_blockstep occupancy target (register-bound)
+constexpr int kColChunks = 64;       // row chunks per column in k_col_dots
+constexpr int kMaxBlockB = 8;
+
+// ---- RCCL through dlopen: only multi-process runs need it ------------------------
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    void* CommInitRank = nullptr;  // (ncclComm_t*, int nranks, ncclUniqueId by value, int rank)
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+struct UniqueId { char bytes[128]; };
+typedef int (*comm_init_rank_fn)(void**, int, UniqueId, int);
+Rccl g_rccl;
+
+bool load_rccl(std::string& err) {
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+        g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) { err = std::string("dlopen librccl failed: ") + dlerror(); return false; }
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(
+        g_rccl.lib, "ncclAllReduce");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) {
+        err = "librccl is missing ncclGetUniqueId/ncclCommInitRank/ncclAllReduce";
+        return false;
+    }
+    return true;
+}
+constexpr int kNcclDouble = 8;  // ncclFloat64
+constexpr int kNcclSum = 0;
+
+}  // namespace
+
+struct cdh_handle_s {
+    int dtype = CDH_F64, loss = CDH_LS, device = 0;
+    int64_t n = 0, n_total = 0, row0 = 0, p = 0, ld = 0, nvec = 0;
+    size_t esz = 8;
+    hipStream_t stream = nullptr;
+    // device
+    void *X = nullptr, *y = nullptr, *r = nullptr, *w = nullptr;
+    double *beta = nullptr, *omega = nullptr;
+    Ctrl* d_ctrl = nullptr;
+    int64_t* d_idx = nullptr;
+    double *d_hs = nullptr, *d_newval = nullptr;
+    int32_t* d_touched = nullptr;
+    double *d_partials = nullptr, *d_red = nullptr, *d_colout = nullptr;
+    int64_t* d_sup_idx = nullptr;
+    double* d_sup_val = nullptr;
+    // pinned host staging
+    int64_t* h_idx = nullptr;
+    double *h_hs = nullptr, *h_newval = nullptr, *h_red = nullptr;
+    int32_t* h_touched = nullptr;
+    Ctrl* h_ctrl = nullptr;
+    // state
+    int64_t cap = 0;          // visits per chunk
+    size_t partials_doubles = 0;
+    Ctrl ctrl{};
+    bool has_omega = false, has_w = false, y_set = false;
+    cdh::SupportList x;
+    int mode = CDH_SWEEP_COORD, blockB = 8;
+    bool use_graph = false;
+    bool domain_error = false;
+    int step_grid = 1, block_grid = 1;
+    // comm
+    void* comm = nullptr;
+    int rank = 0, nranks = 1;
+    // profile
+    bool prof = false;
+    double prof_ms = 0.0, prof_bytes = 0.0;
+    int64_t prof_launches = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            char buf_[512];                                                                 \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                   \
+            (h)->err = buf_;                                                                \
+            return e_ == hipErrorOutOfMemory ? CDH_OOM : CDH_HIP_ERROR;                     \
+        }                                                                                   \
+    } while (0)
+
+#define CHK(call)                                   \
+    do {                                            \
+        int32_t s_ = (call);                        \
+        if (s_ != CDH_OK) return s_;                \
+    } while (0)
+
+int32_t fail(cdh_handle h, int32_t code, const char* msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+template <typename F> int32_t dispatch(cdh_handle h, F&& f) {
+    return h->dtype == CDH_F64 ? f((double*)nullptr) : f((float*)nullptr);
+}
+
+int32_t upload_ctrl(cdh_handle h) {
+    *h->h_ctrl = h->ctrl;
+    HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
+    return CDH_OK;
+}
+
+int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
+    if (!h->comm) return CDH_OK;
+    int rc = g_rccl.AllReduce(dbuf, dbuf, count, kNcclDouble, kNcclSum, h->comm, h->stream);
+    if (rc != 0) {
+        h->err = std::string("ncclAllReduce failed: ") +
+                 (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+        return CDH_RCCL_ERROR;
+    }
+    return CDH_OK;
+}
+
+// ---- column dots over columns [j0, j0+nc): d_colout[2*j + {0,1}] = (x.r (w), x.x (w)) ----
+int32_t col_dots(cdh_handle h, int64_t j0, int64_t nc, const void* rvec, bool use_w) {
+    // batches of at most 4096 columns keep the partial buffer small
+    for (int64_t b0 = 0; b0 < nc; b0 += 4096) {
+        const int64_t bc = std::min<int64_t>(4096, nc - b0);
+        const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(kColChunks, (h->nvec + kBlock - 1) / kBlock));
+        if ((size_t)bc * chunks * 2 > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partials too small");
+        dim3 grid(chunks, (unsigned)bc);
+        CHK(dispatch(h, [&](auto* t) {
+            using T = std::remove_pointer_t<decltype(t)>;
+            hipLaunchKernelGGL(k_col_dots<T>, grid, dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
+                               h->nvec, use_w ? (const T*)h->w : (const T*)nullptr, (const T*)rvec,
+                               j0 + b0, h->d_partials);
+            return CDH_OK;
+        }));
+        hipLaunchKernelGGL(k_col_dots_reduce, dim3((unsigned)bc), dim3(64), 0, h->stream,
+                           h->d_partials, chunks, h->d_colout + 2 * b0);
+        HIPCHK(h, hipGetLastError());
+    }
+    CHK(allreduce(h, h->d_colout, (size_t)(2 * nc)));
+    return CDH_OK;
+}
+
+int32_t resid_moments_dev(cdh_handle h) {  // -> d_red[0..2] = sum r, sum r^2, sum w r^2
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (h->nvec + kBlock - 1) / kBlock));
+    CHK(dispatch(h, [&](auto* t) {
+        using T = std::remove_pointer_t<decltype(t)>;
+        hipLaunchKernelGGL(k_resid_moments<T>, dim3(grid), dim3(kBlock), 0, h->stream, h->nvec,
+                           (const T*)h->r, h->has_w ? (const T*)h->w : (const T*)nullptr, h->d_partials);
+        return CDH_OK;
+    }));
+    hipLaunchKernelGGL(k_sum_records, dim3(1), dim3(kBlock), 0, h->stream, h->d_partials, grid, h->d_red);
+    HIPCHK(h, hipGetLastError());
+    CHK(allreduce(h, h->d_red, 4));
+    return CDH_OK;
+}
+
+// ---- initialize!: upload support, r = y - X beta ------------------------------------
+int32_t rebuild_residual(cdh_handle h) {
+    const int64_t nnz = h->x.nnz();
+    std::vector<double> dense((size_t)h->p, 0.0);
+    for (int64_t s = 0; s < nnz; ++s) dense[(size_t)h->x.coord(s)] = h->x.slot_value(s);
+    HIPCHK(h, hipMemcpyAsync(h->beta, dense.data(), sizeof(double) * h->p, hipMemcpyHostToDevice, h->stream));
+    std::vector<int64_t> si((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<double> sv((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t s = 0; s < nnz; ++s) { si[(size_t)s] = h->x.coord(s); sv[(size_t)s] = h->x.slot_value(s); }
+    if (nnz > 0) {
+        HIPCHK(h, hipMemcpyAsync(h->d_sup_idx, si.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_sup_val, sv.data(), sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
+    }
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (h->nvec + kBlock - 1) / kBlock));
+    CHK(dispatch(h, [&](auto* t) {
+        using T = std::remove_pointer_t<decltype(t)>;
+        hipLaunchKernelGGL(k_init_resid<T>, dim3(grid), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
+                           h->nvec, (const T*)h->y, (T*)h->r, h->d_sup_idx, h->d_sup_val, (int)nnz);
+        return CDH_OK;
+    }));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors above go out of scope
+    return CDH_OK;
+}
+
+// ---- one chunk of a pass: visits idx0[0..m) -------------------------------------------
+template <typename T, int B> void launch_block_chunk(cdh_handle h, int m) {
+    constexpr int NREC = BlockRec<B>::N;
+    const int G = h->block_grid;
+    int nprev = 0;
+    for (int pos0 = 0; pos0 < m; pos0 += B) {
+        const int nb = std::min(B, m - pos0);
+        hipLaunchKernelGGL((k_blockstep<T, B>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
+                           h->nvec, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev, h->d_partials);
+        if (!h->comm) {
+            hipLaunchKernelGGL((k_block_finalize<B, true>), dim3(1), dim3(1024), 0, h->stream,
+                               h->d_partials, G, nb, h->d_ctrl, h->beta, h->omega, h->d_idx, h->d_hs,
+                               h->d_newval, h->d_touched, pos0, h->d_red);
+        } else {
+            hipLaunchKernelGGL((k_block_finalize<B, false>), dim3(1), dim3(1024), 0, h->stream,
+                               h->d_partials, G, nb, h->d_ctrl, h->beta, h->omega, h->d_idx, h->d_hs,
+                               h->d_newval, h->d_touched, pos0, h->d_red);
+            allreduce(h, h->d_red, NREC);
+            hipLaunchKernelGGL((k_block_scalar<B>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb,
+                               h->d_ctrl, h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval,
+                               h->d_touched, pos0);
+        }
+        nprev = nb;
+    }
+    const int last0 = ((m - 1) / B) * B;
+    hipLaunchKernelGGL((k_block_axpy<T, B>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
+                       h->nvec, (T*)h->r, h->d_idx, h->d_hs, last0, m - last0);
+}
+
+template <typename T> void launch_coord_chunk(cdh_handle h, int m) {
+    const int G = h->step_grid;
+    for (int pos = 0; pos < m; ++pos) {
+        if (h->has_w)
+            hipLaunchKernelGGL((k_step<T, true>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X,
+                               h->ld, h->nvec, (const T*)h->w, (T*)h->r, h->d_idx, h->d_hs, pos, h->d_partials);
+        else
+            hipLaunchKernelGGL((k_step<T, false>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X,
+                               h->ld, h->nvec, (const T*)nullptr, (T*)h->r, h->d_idx, h->d_hs, pos, h->d_partials);
+        if (!h->comm) {
+            hipLaunchKernelGGL(k_finalize<true>, dim3(1), dim3(kBlock), 0, h->stream, h->d_partials, G,
+                               h->d_ctrl, h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched,
+                               pos, h->d_red);
+        } else {
+            hipLaunchKernelGGL(k_finalize<false>, dim3(1), dim3(kBlock), 0, h->stream, h->d_partials, G,
+                               h->d_ctrl, h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched,
+                               pos, h->d_red);
+            allreduce(h, h->d_red, 4);
+            hipLaunchKernelGGL(k_scalar_update, dim3(1), dim3(64), 0, h->stream, h->d_red, h->d_ctrl,
+                               h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos);
+        }
+    }
+    hipLaunchKernelGGL(k_axpy<T>, dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld, h->nvec,
+                       (T*)h->r, h->d_idx, h->d_hs, m);
+}
+
+int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
+    std::memcpy(h->h_idx, idx0, sizeof(int64_t) * (size_t)m);
+    HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+    h->ctrl.maxH = 0.0;
+    h->ctrl.domain_error = 0;
+    CHK(upload_ctrl(h));
+    if (h->prof) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    const bool blocked = (h->mode == CDH_SWEEP_BLOCK) && !h->has_w;
+    CHK(dispatch(h, [&](auto* t) {
+        using T = std::remove_pointer_t<decltype(t)>;
+        if (!blocked) launch_coord_chunk<T>(h, m);
+        else if (h->blockB == 8) launch_block_chunk<T, 8>(h, m);
+        else if (h->blockB == 4) launch_block_chunk<T, 4>(h, m);
+        else launch_block_chunk<T, 2>(h, m);
+        return CDH_OK;
+    }));
+    HIPCHK(h, hipGetLastError());
+    if (h->prof) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_hs, h->d_hs, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_newval, h->d_newval, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_touched, h->d_touched, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->h_ctrl->domain_error) h->domain_error = true;
+    const double mh = h->h_ctrl->maxH;
+    if (mh > *maxH || mh != mh) *maxH = mh;
+    // replay the SparseIterate writes of the visits in order (x[k] += b/a ; cdprox!)
+    for (int i = 0; i < m; ++i) {
+        const int64_t k = idx0[i];
+        if (h->h_touched[i] && h->x.get(k) == 0.0) h->x.set(k, 1.0);  // pre-prox non-zero: slot appended
+        h->x.set(k, h->h_newval[i]);
+    }
+    if (h->prof) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        h->prof_ms += ms;
+        const double vec = (double)h->n * (double)h->esz;
+        if (!blocked) {
+            h->prof_launches += m;
+            for (int i = 0; i < m; ++i) {
+                const bool ap = i > 0 && h->h_hs[i - 1] != 0.0;
+                h->prof_bytes += vec * ((h->has_w ? 3.0 : 2.0) + (ap ? 2.0 : 0.0));
+            }
+            if (h->h_hs[m - 1] != 0.0) h->prof_bytes += 3.0 * vec;
+        } else {
+            const int B = h->blockB;
+            for (int pos0 = 0; pos0 < m; pos0 += B) {
+                const int nb = std::min(B, m - pos0);
+                int nzp = 0;
+                for (int i = std::max(0, pos0 - B); i < pos0; ++i) nzp += h->h_hs[i] != 0.0;
+                h->prof_bytes += vec * (nb + 1 + nzp + (nzp ? 1 : 0));
+                h->prof_launches += 1;
+            }
+            int nzl = 0;
+            for (int i = ((m - 1) / B) * B; i < m; ++i) nzl += h->h_hs[i] != 0.0;
+            if (nzl) h->prof_bytes += vec * (nzl + 2);
+        }
+    }
+    return CDH_OK;
+}
+
+// _cdPass! (coordinate_descent.jl:94-110)
+int32_t run_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH) {
+    *maxH = 0.0;
+    for (int64_t off = 0; off < m; off += h->cap) {
+        const int mm = (int)std::min<int64_t>(h->cap, m - off);
+        CHK(run_chunk(h, idx0 + off, mm, maxH));
+    }
+    h->x.dropzeros();
+    return CDH_OK;
+}
+
+// _coordinateDescent! (coordinate_descent.jl:65-92)
+int32_t solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched, cdh_stats* st) {
+    bool prev_converged = false, converged = true;
+    std::vector<int64_t> visit;
+    st->converged = 0;
+    for (int64_t iter = 0; iter < o->maxIter; ++iter) {
+        const bool full = converged;
+        sched.next_pass(h->x, full, visit);
+        double maxH = 0.0;
+        if (!visit.empty()) CHK(run_pass(h, visit.data(), (int64_t)visit.size(), &maxH));
+        else h->x.dropzeros();
+        st->passes += 1; st->visits += (int64_t)visit.size(); st->maxH = maxH;
+        if (full) st->full_passes += 1;
+        prev_converged = converged;
+        converged = maxH < o->optTol;
+        if (prev_converged && converged) { st->converged = 1; break; }
+    }
+    st->domain_error = h->domain_error ? 1 : 0;
+    return CDH_OK;
+}
+
+int32_t lambda_max(cdh_handle h, double* out) {
+    CHK(col_dots(h, 0, h->p, h->r, h->loss == CDH_WLS));
+    std::vector<double> cd((size_t)(2 * h->p));
+    HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * h->p, hipMemcpyDeviceToHost, h->stream));
+    double denom = (double)h->n_total;
+    if (h->loss == CDH_SQRT) {
+        CHK(resid_moments_dev(h));
+        HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->loss == CDH_SQRT) denom = std::sqrt(h->h_red[1]);
+    std::vector<double> om;
+    if (h->has_omega) {
+        om.resize((size_t)h->p);
+        HIPCHK(h, hipMemcpy(om.data(), h->omega, sizeof(double) * h->p, hipMemcpyDeviceToHost));
+    }
+    double lmax = 0.0;
+    for (int64_t k = 0; k < h->p; ++k) {
+        double t = std::fabs(-cd[(size_t)(2 * k)] / denom);
+        if (h->has_omega) t /= om[(size_t)k];
+        if (t > lmax) lmax = t;
+    }
+    *out = lmax;
+    return CDH_OK;
+}
+
+void free_all(cdh_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    void* dev[] = {h->X, h->y, h->r, h->w, h->beta, h->omega, h->d_ctrl, h->d_idx, h->d_hs, h->d_newval,
+                   h->d_touched, h->d_partials, h->d_red, h->d_colout, h->d_sup_idx, h->d_sup_val};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    void* pin[] = {h->h_idx, h->h_hs, h->h_newval, h->h_red, h->h_touched, h->h_ctrl};
+    for (void* p : pin) if (p) (void)hipHostFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+}  // namespace
+
+// ====================================================================================
+extern "C" {
+
+int32_t cdh_device_count(int32_t* out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); *out = 0; return CDH_HIP_ERROR; }
+    *out = n;
+    return CDH_OK;
+}
+
+const char* cdh_last_error(cdh_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local, int64_t n_total,
+                   int64_t row_offset, int64_t p, int32_t device) {
+    if (!out) return fail(nullptr, CDH_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    if (dtype != CDH_F64 && dtype != CDH_F32) return fail(nullptr, CDH_BAD_ARG, "dtype must be CDH_F64 or CDH_F32");
+    if (loss != CDH_LS && loss != CDH_SQRT && loss != CDH_WLS) return fail(nullptr, CDH_BAD_ARG, "unknown loss");
+    if (n_local <= 0 || p <= 0 || n_total < n_local || row_offset < 0 || row_offset + n_local > n_total)
+        return fail(nullptr, CDH_DIM_MISMATCH, "need 0 < n_local <= n_total, p > 0, shard inside [0, n_total)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, CDH_HIP_ERROR, "no HIP device: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, CDH_BAD_ARG, "device index out of range");
+    cdh_handle h = new cdh_handle_s();
+    h->dtype = dtype; h->loss = loss; h->device = device;
+    h->n = n_local; h->n_total = n_total; h->row0 = row_offset; h->p = p;
+    h->esz = dtype == CDH_F64 ? 8 : 4;
+    const int NV = dtype == CDH_F64 ? 2 : 4;
+    h->ld = round_up(n_local, 32);            // every column starts 128/256-B aligned
+    h->nvec = round_up(n_local, NV) / NV;     // pad rows [n, ld) are zero in X, y, r, w
+    h->cap = std::max<int64_t>(p, 4096);
+    h->x.resize(p);
+    int32_t rc = [&]() -> int32_t {
+        HIPCHK(h, hipSetDevice(device));
+        HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreate(&h->ev0));
+        HIPCHK(h, hipEventCreate(&h->ev1));
+        hipDeviceProp_t prop;
+        HIPCHK(h, hipGetDeviceProperties(&prop, device));
+        const int cus = std::max(1, prop.multiProcessorCount);
+        const int64_t want = (h->nvec + (int64_t)kBlock * kUnroll - 1) / ((int64_t)kBlock * kUnroll);
+        h->step_grid = (int)std::max<int64_t>(1, std::min<int64_t>({want, (int64_t)kMaxStepGrid, (int64_t)cus * 8}));
+        const int64_t wantb = (h->nvec + kBlock - 1) / kBlock;
+        h->block_grid = (int)std::max<int64_t>(1, std::min<int64_t>(wantb, (int64_t)cus * kBlockGridPerCU));
+        const size_t colbytes = (size_t)h->ld * h->esz;
+        HIPCHK(h, hipMalloc(&h->X, colbytes * (size_t)p));
+        HIPCHK(h, hipMalloc(&h->y, colbytes));
+        HIPCHK(h, hipMalloc(&h->r, colbytes));
+        HIPCHK(h, hipMemsetAsync(h->y, 0, colbytes, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->r, 0, colbytes, h->stream));
+        if (loss == CDH_WLS) {
+            HIPCHK(h, hipMalloc(&h->w, colbytes));
+            HIPCHK(h, hipMemsetAsync(h->w, 0, colbytes, h->stream));
+        }
+        HIPCHK(h, hipMalloc(&h->beta, sizeof(double) * p));
+        HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * p, h->stream));
+        HIPCHK(h, hipMalloc(&h->omega, sizeof(double) * p));
+        HIPCHK(h, hipMalloc(&h->d_ctrl, sizeof(Ctrl)));
+        HIPCHK(h, hipMalloc(&h->d_idx, sizeof(int64_t) * h->cap));
+        HIPCHK(h, hipMalloc(&h->d_hs, sizeof(double) * h->cap));
+        HIPCHK(h, hipMalloc(&h->d_newval, sizeof(double) * h->cap));
+        HIPCHK(h, hipMalloc(&h->d_touched, sizeof(int32_t) * h->cap));
+        h->partials_doubles = std::max<size_t>({(size_t)kMaxStepGrid * kNSum,
+                                                (size_t)cus * kBlockGridPerCU * BlockRec<kMaxBlockB>::N,
+                                                (size_t)4096 * kColChunks * 2});
+        HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * h->partials_doubles));
+        HIPCHK(h, hipMalloc(&h->d_red, sizeof(double) * 64));
+        HIPCHK(h, hipMalloc(&h->d_colout, sizeof(double) * 2 * p));
+        HIPCHK(h, hipMalloc(&h->d_sup_idx, sizeof(int64_t) * p));
+        HIPCHK(h, hipMalloc(&h->d_sup_val, sizeof(double) * p));
+        HIPCHK(h, hipHostMalloc(&h->h_idx, sizeof(int64_t) * h->cap));
+        HIPCHK(h, hipHostMalloc(&h->h_hs, sizeof(double) * h->cap));
+        HIPCHK(h, hipHostMalloc(&h->h_newval, sizeof(double) * h->cap));
+        HIPCHK(h, hipHostMalloc(&h->h_touched, sizeof(int32_t) * h->cap));
+        HIPCHK(h, hipHostMalloc(&h->h_red, sizeof(double) * 64));
+        HIPCHK(h, hipHostMalloc(&h->h_ctrl, sizeof(Ctrl)));
+        // zero the pad rows of X once (uploads / the generator only write rows < n)
+        if (h->ld > h->n) HIPCHK(h, hipMemsetAsync(h->X, 0, colbytes * (size_t)p, h->stream));
+        h->ctrl.lambda0 = 0.0; h->ctrl.n_total = (double)n_total; h->ctrl.maxH = 0.0;
+        h->ctrl.loss = loss; h->ctrl.has_omega = 0; h->ctrl.domain_error = 0;
+        CHK(upload_ctrl(h));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return CDH_OK;
+    }();
+    if (rc != CDH_OK) { g_create_error = h->err; free_all(h); return rc; }
+    *out = h;
+    return CDH_OK;
+}
+
+int32_t cdh_destroy(cdh_handle h) {
+    if (!h) return CDH_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    free_all(h);
+    return CDH_OK;
+}
+
+int32_t cdh_synchronize(cdh_handle h) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+
+int32_t cdh_set_X_cols(cdh_handle h, int64_t j0, int64_t ncols, const void* host, int64_t ld) {
+    if (j0 < 0 || ncols < 0 || j0 + ncols > h->p || ld < h->n) return fail(h, CDH_DIM_MISMATCH, "column block outside X");
+    if (ncols == 0) return CDH_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy2DAsync((char*)h->X + (size_t)j0 * h->ld * h->esz, (size_t)h->ld * h->esz, host,
+                               (size_t)ld * h->esz, (size_t)h->n * h->esz, (size_t)ncols,
+                               hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+
+int32_t cdh_get_X_cols(cdh_handle h, int64_t j0, int64_t ncols, void* host, int64_t ld) {
+    if (j0 < 0 || ncols < 0 || j0 + ncols > h->p || ld < h->n) return fail(h, CDH_DIM_MISMATCH, "column block outside X");
+    if (ncols == 0) return CDH_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy2DAsync(host, (size_t)ld * h->esz, (char*)h->X + (size_t)j0 * h->ld * h->esz,
+                               (size_t)h->ld * h->esz, (size_t)h->n * h->esz, (size_t)ncols,
+                               hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+
+int32_t cdh_set_y(cdh_handle h, const void* host_y) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->y, host_y, (size_t)h->n * h->esz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->r, h->y, (size_t)h->n * h->esz, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->y_set = true;
+    return CDH_OK;
+}
+
+int32_t cdh_get_y(cdh_handle h, void* host_y) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(host_y, h->y, (size_t)h->n * h->esz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+
+int32_t cdh_set_obs_weights(cdh_handle h, const void* host_w) {
+    if (h->loss != CDH_WLS) return fail(h, CDH_BAD_ARG, "observation weights need the CDH_WLS loss");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->w, host_w, (size_t)h->n * h->esz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->has_w = true;
+    return CDH_OK;
+}
+
+int32_t cdh_generate(cdh_handle h, uint64_t seed, int64_t s, double noise, double* out_beta_star) {
+    if (s < 0 || s > h->p) return fail(h, CDH_BAD_ARG, "need 0 <= s <= p");
+    HIPCHK(h, hipSetDevice(h->device));
+    // planted coefficients: beta*_j = z_j (1 + u_j) (benchmark/cd_bench.jl:14), stream 2
+    std::vector<double> bstar((size_t)std::max<int64_t>(s, 1), 0.0);
+    for (int64_t j = 0; j < s; ++j) {
+        double u1, u2;
+        const double z = Philox::normal(seed, (uint64_t)(2 * j), 0u, 2u);
+        Philox::uniforms(seed, (uint64_t)j, 1u, 2u, u1, u2);
+        bstar[(size_t)j] = z * (1.0 + u1);
+    }
+    if (out_beta_star) std::memcpy(out_beta_star, bstar.data(), sizeof(double) * (size_t)s);
+    HIPCHK(h, hipMemcpyAsync(h->d_sup_val, bstar.data(), sizeof(double) * bstar.size(), hipMemcpyHostToDevice, h->stream));
+    const int64_t pairs = (h->n + 3) / 2;
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (pairs + kBlock - 1) / kBlock));
+    for (int64_t j0 = 0; j0 < h->p; j0 += 32768) {
+        const int64_t nc = std::min<int64_t>(32768, h->p - j0);
+        CHK(dispatch(h, [&](auto* t) {
+            using T = std::remove_pointer_t<decltype(t)>;
+            hipLaunchKernelGGL(k_gen_X<T>, dim3(gx, (unsigned)nc), dim3(kBlock), 0, h->stream, (T*)h->X,
+                               h->ld, h->n, h->row0, j0, seed);
+            return CDH_OK;
+        }));
+    }
+    const int gy = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (h->n + kBlock - 1) / kBlock));
+    CHK(dispatch(h, [&](auto* t) {
+        using T = std::remove_pointer_t<decltype(t)>;
+        hipLaunchKernelGGL(k_gen_y<T>, dim3(gy), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld, h->n,
+                           h->row0, s, h->d_sup_val, noise, seed, (T*)h->y, (T*)h->r);
+        return CDH_OK;
+    }));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->y_set = true;
+    h->x.clear();
+    HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+
+int32_t cdh_set_penalty(cdh_handle h, double lambda0, const double* omega, int64_t n_omega) {
+    HIPCHK(h, hipSetDevice(h->device));
+    if (omega) {
+        if (n_omega != h->p) return fail(h, CDH_DIM_MISMATCH, "length(g.lambda) != numCoordinates(f)");
+        HIPCHK(h, hipMemcpyAsync(h->omega, omega, sizeof(double) * h->p, hipMemcpyHostToDevice, h->stream));
+        h->has_omega = true;
+    } else {
+        h->has_omega = false;
+    }
+    h->ctrl.lambda0 = lambda0;
+    h->ctrl.has_omega = h->has_omega ? 1 : 0;
+    CHK(upload_ctrl(h));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+
+int32_t cdh_num_coordinates(cdh_handle h, int64_t* out) { *out = h->p; return CDH_OK; }
+
+int32_t cdh_set_iterate(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t* idx1, const double* val) {
+    if (x_length != h->p) return fail(h, CDH_DIM_MISMATCH, "numCoordinates(x) != numCoordinates(f)");
+    if (nnz < 0 || nnz > h->p) return fail(h, CDH_BAD_ARG, "nnz out of range");
+    for (int64_t i = 0; i < nnz; ++i)
+        if (idx1[i] < 1 || idx1[i] > h->p) return fail(h, CDH_BAD_ARG, "support index out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    h->x.clear();
+    for (int64_t i = 0; i < nnz; ++i) {
+        // a stored zero keeps its slot in the reference's SparseIterate; mirror that
+        if (val[i] == 0.0) { h->x.set(idx1[i] - 1, 1.0); h->x.set(idx1[i] - 1, 0.0); }
+        else h->x.set(idx1[i] - 1, val[i]);
+    }
+    std::vector<double> dense((size_t)h->p, 0.0);
+    for (int64_t s = 0; s < h->x.nnz(); ++s) dense[(size_t)h->x.coord(s)] = h->x.slot_value(s);
+    HIPCHK(h, hipMemcpyAsync(h->beta, dense.data(), sizeof(double) * h->p, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+
+int32_t cdh_initialize(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t* idx1, const double* val) {
+    CHK(cdh_set_iterate(h, x_length, nnz, idx1, val));
+    return rebuild_residual(h);
+}
+
+int32_t cdh_gradient(cdh_handle h, int64_t k1, double* out) {
+    if (k1 < 1 || k1 > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    CHK(col_dots(h, k1 - 1, 1, h->r, h->loss == CDH_WLS));
+    HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_colout, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
+    double denom = (double)h->n_total;
+    double xr;
+    if (h->loss == CDH_SQRT) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        xr = h->h_red[0];
+        CHK(resid_moments_dev(h));
+        HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        denom = std::sqrt(h->h_red[1]);
+    } else {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        xr = h->h_red[0];
+    }
+    *out = -xr / denom;
+    return CDH_OK;
+}
+
+int32_t cdh_descend(cdh_handle h, int64_t k1, double* out_h) {
+    if (k1 < 1 || k1 > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t k0 = k1 - 1;
+    double maxH = 0.0;
+    const int save_mode = h->mode;
+    h->mode = CDH_SWEEP_COORD;
+    int32_t rc = run_chunk(h, &k0, 1, &maxH);  // no dropzeros!: that is _cdPass!'s job
+    h->mode = save_mode;
+    if (rc != CDH_OK) return rc;
+    *out_h = h->h_hs[0];
+    return CDH_OK;
+}
+
+int32_t cdh_lambda_max(cdh_handle h, double* out) {
+    HIPCHK(h, hipSetDevice(h->device));
+    return lambda_max(h, out);
+}
+
+int32_t cdh_pass(cdh_handle h, int64_t m, const int64_t* idx1, double* out_maxH) {
+    if (m < 0) return fail(h, CDH_BAD_ARG, "m < 0");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<int64_t> idx0((size_t)m);
+    for (int64_t i = 0; i < m; ++i) {
+        if (idx1[i] < 1 || idx1[i] > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
+        idx0[(size_t)i] = idx1[i] - 1;
+    }
+    double maxH = 0.0;
+    if (m > 0) CHK(run_pass(h, idx0.data(), m, &maxH));
+    else h->x.dropzeros();
+    if (out_maxH) *out_maxH = maxH;
+    return CDH_OK;
+}
+
+int32_t cdh_solve(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
+    HIPCHK(h, hipSetDevice(h->device));
+    cdh_stats st{};
+    cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
+    int32_t rc = solve(h, opt, sched, &st);
+    if (out) *out = st;
+    return rc;
+}
+
+int32_t cdh_coordinate_descent(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
+    HIPCHK(h, hipSetDevice(h->device));
+    cdh_stats st{};
+    cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
+    h->domain_error = false;
+    int32_t rc = CDH_OK;
+    if (opt->warmStart) {
+        CHK(rebuild_residual(h));                       // initialize!(f, x)     (:21)
+        rc = solve(h, opt, sched, &st);
+    } else {
+        h->x.clear();                                   // fill!(x, 0)           (:25)
+        CHK(rebuild_residual(h));                       // initialize!(f, x)     (:26)
+        double lmax = 0.0;
+        CHK(lambda_max(h, &lmax));                      // _findLambdaMax        (:29)
+        st.lambda_max = lmax;
+        const double target = h->ctrl.lambda0;
+        const double l1 = std::log(lmax), l2 = std::log(target);
+        const double step = (l2 - l1) / (double)opt->numSteps;
+        if (step == 0.0 || step != step) {
+            rc = fail(h, CDH_BAD_ARG, "cold start: the range log(lambda_max):step:log(lambda0) has a zero step");
+        } else {
+            for (int64_t j = 0; j <= opt->numSteps && rc == CDH_OK; ++j) {  // (:32-36)
+                const double l = (j == opt->numSteps) ? l2 : l1 + (double)j * step;
+                h->ctrl.lambda0 = std::exp(l);
+                rc = solve(h, opt, sched, &st);
+            }
+        }
+        h->ctrl.lambda0 = target;  // g itself is never mutated by the reference
+        CHK(upload_ctrl(h));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    if (out) *out = st;
+    return rc;
+}
+
+int32_t cdh_get_beta(cdh_handle h, double* out_p) {
+    std::memset(out_p, 0, sizeof(double) * (size_t)h->p);
+    for (int64_t s = 0; s < h->x.nnz(); ++s) out_p[h->x.coord(s)] = h->x.slot_value(s);
+    return CDH_OK;
+}
+
+int32_t cdh_get_support(cdh_handle h, int64_t* out_idx1, int64_t* out_nnz) {
+    for (int64_t s = 0; s < h->x.nnz(); ++s) out_idx1[s] = h->x.coord(s) + 1;
+    *out_nnz = h->x.nnz();
+    return CDH_OK;
+}
+
+int32_t cdh_get_residual(cdh_handle h, void* out_n_local) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(out_n_local, h->r, (size_t)h->n * h->esz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+
+int32_t cdh_col_rms(cdh_handle h, double* out_p) {
+    HIPCHK(h, hipSetDevice(h->device));
+    CHK(col_dots(h, 0, h->p, h->r, false));
+    std::vector<double> cd((size_t)(2 * h->p));
+    HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * h->p, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int64_t j = 0; j < h->p; ++j) out_p[j] = std::sqrt(cd[(size_t)(2 * j + 1)] / (double)h->n_total);
+    return CDH_OK;
+}
+
+int32_t cdh_xt_r(cdh_handle h, double* out_p) {
+    HIPCHK(h, hipSetDevice(h->device));
+    CHK(col_dots(h, 0, h->p, h->r, false));
+    std::vector<double> cd((size_t)(2 * h->p));
+    HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * h->p, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int64_t j = 0; j < h->p; ++j) out_p[j] = cd[(size_t)(2 * j)];
+    return CDH_OK;
+}
+
+int32_t cdh_resid_moments(cdh_handle h, double* out_sum, double* out_sumsq) {
+    HIPCHK(h, hipSetDevice(h->device));
+    CHK(resid_moments_dev(h));
+    HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (out_sum) *out_sum = h->h_red[0];
+    if (out_sumsq) *out_sumsq = h->h_red[1];
+    return CDH_OK;
+}
+
+int32_t cdh_objective(cdh_handle h, double* out) {
+    HIPCHK(h, hipSetDevice(h->device));
+    CHK(resid_moments_dev(h));
+    HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> om;
+    if (h->has_omega) {
+        om.resize((size_t)h->p);
+        HIPCHK(h, hipMemcpyAsync(om.data(), h->omega, sizeof(double) * h->p, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double pen = 0.0;
+    for (int64_t s = 0; s < h->x.nnz(); ++s)
+        pen += std::fabs(h->x.slot_value(s)) * (h->has_omega ? om[(size_t)h->x.coord(s)] : 1.0);
+    pen *= h->ctrl.lambda0;
+    const double ss = h->loss == CDH_WLS ? h->h_red[2] : h->h_red[1];
+    *out = (h->loss == CDH_SQRT ? std::sqrt(ss) : ss / (2.0 * (double)h->n_total)) + pen;
+    return CDH_OK;
+}
+
+int32_t cdh_set_sweep_mode(cdh_handle h, int32_t mode, int32_t block) {
+    if (mode != CDH_SWEEP_COORD && mode != CDH_SWEEP_BLOCK) return fail(h, CDH_BAD_ARG, "unknown sweep mode");
+    if (mode == CDH_SWEEP_BLOCK && block != 2 && block != 4 && block != 8)
+        return fail(h, CDH_BAD_ARG, "block size must be 2, 4 or 8");
+    h->mode = mode;
+    if (mode == CDH_SWEEP_BLOCK) h->blockB = block;
+    return CDH_OK;
+}
+
+int32_t cdh_set_use_graph(cdh_handle h, int32_t on) { h->use_graph = on != 0; return CDH_OK; }
+
+int32_t cdh_comm_unique_id(void* out_128_bytes) {
+    std::string err;
+    if (!load_rccl(err)) { g_create_error = err; return CDH_RCCL_ERROR; }
+    UniqueId id;
+    std::memset(&id, 0, sizeof id);
+    if (g_rccl.GetUniqueId(&id) != 0) { g_create_error = "ncclGetUniqueId failed"; return CDH_RCCL_ERROR; }
+    std::memcpy(out_128_bytes, &id, sizeof id);
+    return CDH_OK;
+}
+
+int32_t cdh_comm_init(cdh_handle h, const void* id_128_bytes, int32_t rank, int32_t nranks) {
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, CDH_BAD_ARG, "bad rank / nranks");
+    // a 1-rank communicator is only built when asked for (exercises the RCCL path on one GPU)
+    if (nranks == 1 && !getenv("CDH_FORCE_RCCL")) { h->rank = 0; h->nranks = 1; return CDH_OK; }
+    std::string err;
+    if (!load_rccl(err)) { h->err = err; return CDH_RCCL_ERROR; }
+    HIPCHK(h, hipSetDevice(h->device));
+    UniqueId id;
+    std::memcpy(&id, id_128_bytes, sizeof id);
+    int rc = ((comm_init_rank_fn)g_rccl.CommInitRank)(&h->comm, nranks, id, rank);
+    if (rc != 0) {
+        h->err = std::string("ncclCommInitRank failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+        return CDH_RCCL_ERROR;
+    }
+    h->rank = rank; h->nranks = nranks;
+    return CDH_OK;
+}
+
+int32_t cdh_profile_begin(cdh_handle h) {
+    h->prof = true; h->prof_ms = 0.0; h->prof_bytes = 0.0; h->prof_launches = 0;
+    return CDH_OK;
+}
+
+int32_t cdh_profile_end(cdh_handle h, double* out_ms, int64_t* out_launches, double* out_algorithmic_bytes) {
+    h->prof = false;
+    if (out_ms) *out_ms = h->prof_ms;
+    if (out_launches) *out_launches = h->prof_launches;
+    if (out_algorithmic_bytes) *out_algorithmic_bytes = h->prof_bytes;
+    return CDH_OK;
+}
+
+}  // extern "C"

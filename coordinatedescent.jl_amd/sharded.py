@@ -1,0 +1,98 @@
+"""Row-sharded multi-process driver: one process per GPU, the n (sample) dimension
+split into contiguous row blocks, beta / omega / every scalar replicated.
+
+The data path's only exchange step is the sum of the per-coordinate (or per-block)
+gradient scalars, done INSIDE the HIP library with an RCCL all-reduce on the sweep
+stream (csrc/cdhip.hip `allreduce`).  This module is the control plane around it:
+row partition, rendezvous, broadcasting RCCL's unique id, and max-over-ranks timing.
+`torch.distributed` is used for that only (gloo works; no tensors of the path go
+through it).  The reference has no distributed code; the
+sharding follows SURVEY.md section 8(e).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+
+def shard_rows(n_total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous, near-equal row blocks: returns (row_offset, n_local).  Every row
+    belongs to exactly one rank; the first n_total % world ranks get one extra row."""
+    if not (0 <= rank < world) or n_total < world:
+        raise ValueError("need 0 <= rank < world <= n_total")
+    base, extra = divmod(n_total, world)
+    n_local = base + (1 if rank < extra else 0)
+    row_offset = rank * base + min(rank, extra)
+    return row_offset, n_local
+
+
+def env_rank_world() -> tuple[int, int, int]:
+    """(rank, local_rank, world) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+class ControlPlane:
+    """Rendezvous + tiny host-side collectives.  world == 1 needs no torch at all."""
+
+    def __init__(self, backend: str = "gloo"):
+        self.rank, self.local_rank, self.world = env_rank_world()
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def broadcast_bytes(self, payload: bytes | None, nbytes: int, src: int = 0) -> bytes:
+        if self.dist is None:
+            return payload
+        import torch
+        t = torch.zeros(nbytes, dtype=torch.uint8)
+        if self.rank == src:
+            t[:] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        self.dist.broadcast(t, src=src)
+        return bytes(t.numpy().tobytes())
+
+    def max_over_ranks(self, value: float) -> float:
+        if self.dist is None:
+            return value
+        import torch
+        t = torch.tensor([value], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value: float) -> float:
+        if self.dist is None:
+            return value
+        import torch
+        t = torch.tensor([value], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def shutdown(self):
+        if self.dist is not None and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+def connect(loss, cp: ControlPlane):
+    """Give `loss` (a row shard) its RCCL communicator: rank 0 draws the unique id, the
+    control plane broadcasts the 128 bytes, every rank calls cdh_comm_init."""
+    from . import _lib
+    L = _lib.lib()
+    uid = None
+    force = bool(os.environ.get("CDH_FORCE_RCCL"))
+    if cp.world == 1 and not force:
+        return loss
+    if cp.rank == 0:
+        buf = C.create_string_buffer(128)
+        _lib.check(L.cdh_comm_unique_id(buf), None)
+        uid = buf.raw
+    uid = cp.broadcast_bytes(uid, 128, src=0)
+    loss.comm_init(uid, cp.rank, cp.world)
+    return loss

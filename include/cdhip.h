@@ -1,0 +1,188 @@
+/*
+ * cdhip.h -- C ABI of the MI355X-native coordinate-descent sweep.
+ *
+ * This is the drop-in boundary for ONE path of mlakolar/CoordinateDescent.jl
+ * v0.3.0: coordinateDescent! -> _coordinateDescent! -> _cdPass! ->
+ * descendCoordinate! for CDLeastSquaresLoss / CDSqrtLassoLoss (/ CDWeightedLSLoss)
+ * with a ProxL1 penalty, plus the helpers that path calls (initialize!, gradient,
+ * _findLambdaMax, _stdX!).  Each entry point names the reference interface it
+ * replaces (paths relative to the reference's src/).  The Julia binding a
+ * maintainer would add is in INTEGRATION.md and julia/CoordinateDescentHIP.jl.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every function returns a cdh_status.
+ *   - Coordinates cross the ABI 1-based int64 (Julia's Int64), rebased inside.
+ *   - Host arrays are borrowed for the duration of the call only.
+ *   - X is column-major n x p with leading dimension ld (elements), dtype T;
+ *     y, r, w are length-n vectors of T; beta/omega and all scalars are double.
+ *   - One process drives one GPU.  With several processes each handle owns the
+ *     row shard [row_offset, row_offset + n_local) of an n_total-row problem and
+ *     the per-coordinate gradient scalars are summed with an RCCL all-reduce
+ *     (cdh_comm_init).  beta, omega and every scalar are replicated.
+ *   - A handle is not thread-safe; calls block until results are host-visible.
+ *   - Nothing here falls back to a CPU path: without a GPU cdh_create fails
+ *     with CDH_HIP_ERROR.
+ */
+#ifndef CDHIP_H
+#define CDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cdh_handle_s *cdh_handle;
+
+/* Julia exceptions the codes map to: DIM_MISMATCH -> DimensionMismatch
+ * (coordinate_descent.jl:13,15; cd_differentiable_function.jl:53,129,212),
+ * BAD_ARG -> ArgumentError (lasso.jl:128; the zero-step cold-start range),
+ * DOMAIN -> DomainError (sqrt of a negative, cd_differentiable_function.jl:280,282). */
+typedef enum cdh_status {
+    CDH_OK = 0,
+    CDH_DIM_MISMATCH = 1,
+    CDH_BAD_ARG = 2,
+    CDH_DOMAIN = 3,
+    CDH_HIP_ERROR = 4,
+    CDH_RCCL_ERROR = 5,
+    CDH_OOM = 6
+} cdh_status;
+
+typedef enum cdh_dtype { CDH_F64 = 0, CDH_F32 = 1 } cdh_dtype;
+
+/* CDLeastSquaresLoss (cd_differentiable_function.jl:43-111), CDSqrtLassoLoss
+ * (:202-291), CDWeightedLSLoss (:118-194). */
+typedef enum cdh_loss { CDH_LS = 0, CDH_SQRT = 1, CDH_WLS = 2 } cdh_loss;
+
+/* How a pass is executed on the device (no reference counterpart).
+ *  CDH_SWEEP_COORD : one fused kernel per coordinate visit (apply the previous
+ *                    visit's residual update, then the dots of this column),
+ *                    one gradient all-reduce per coordinate.
+ *  CDH_SWEEP_BLOCK : visits are taken B at a time; one kernel reads the B
+ *                    columns once and returns X_B'r and the B x B Gram block, the
+ *                    B scalar updates run on those numbers (algebraically the
+ *                    same iterates), then one rank-B residual update.  One
+ *                    all-reduce per block.  LS and SQRT losses only. */
+typedef enum cdh_sweep_mode { CDH_SWEEP_COORD = 0, CDH_SWEEP_BLOCK = 1 } cdh_sweep_mode;
+
+/* CDOptions (utils.jl:7-20), field for field, + the seed of the substitute RNG
+ * (the reference's RandomIterator uses Julia's global RNG, atom_iterator.jl:60). */
+typedef struct cdh_options {
+    int64_t maxIter;   /* 2000 */
+    double optTol;     /* 1e-7 */
+    int32_t randomize; /* 1    */
+    int32_t warmStart; /* 1    */
+    int64_t numSteps;  /* 50   */
+    uint64_t seed;
+} cdh_options;
+
+/* The reference reports nothing (maxIter exhaustion is silent,
+ * coordinate_descent.jl:74-91); this is a strict superset. */
+typedef struct cdh_stats {
+    int64_t passes;
+    int64_t full_passes;
+    int64_t visits;
+    int32_t converged;
+    int32_t domain_error;
+    double maxH;       /* of the last pass */
+    double lambda_max; /* cold start only  */
+} cdh_stats;
+
+/* ---- lifetime -------------------------------------------------------------- */
+/* Replaces the CDLeastSquaresLoss / CDSqrtLassoLoss / CDWeightedLSLoss outer
+ * constructors (cd_differentiable_function.jl:52-55, 211-214, 128-131): allocates
+ * X, y, r (and w) on `device`.  Single process: n_local == n_total, row_offset 0. */
+int32_t cdh_create(cdh_handle *out, int32_t dtype, int32_t loss, int64_t n_local,
+                   int64_t n_total, int64_t row_offset, int64_t p, int32_t device);
+int32_t cdh_destroy(cdh_handle h);
+const char *cdh_last_error(cdh_handle h); /* h may be NULL: last create error */
+int32_t cdh_device_count(int32_t *out);
+int32_t cdh_synchronize(cdh_handle h);
+
+/* ---- data ------------------------------------------------------------------ */
+/* Upload columns [j0, j0+ncols) (0-based here: a bulk-transfer helper, not a
+ * coordinate) of the local row shard from a host column-major block. */
+int32_t cdh_set_X_cols(cdh_handle h, int64_t j0, int64_t ncols, const void *host, int64_t ld);
+int32_t cdh_get_X_cols(cdh_handle h, int64_t j0, int64_t ncols, void *host, int64_t ld);
+/* y (and r = copy(y), as the loss constructors do). */
+int32_t cdh_set_y(cdh_handle h, const void *host_y);
+int32_t cdh_get_y(cdh_handle h, void *host_y);
+/* Observation weights of CDWeightedLSLoss. */
+int32_t cdh_set_obs_weights(cdh_handle h, const void *host_w);
+/* Synthetic Gaussian problem generated on the device from a counter-based
+ * generator keyed (seed, global row, column), shapes of benchmark/cd_bench.jl:
+ * 8-14: X_ij ~ N(0,1), beta*_j = z_j (1 + u_j) for j < s, y = X beta* + noise e.
+ * out_beta_star (may be NULL) receives the s planted values. */
+int32_t cdh_generate(cdh_handle h, uint64_t seed, int64_t s, double noise, double *out_beta_star);
+
+/* ---- penalty: ProxL1(lambda0) / ProxL1(lambda0, omega) (ProximalBase) -------- */
+/* omega == NULL means unweighted; otherwise n_omega must equal p
+ * (coordinate_descent.jl:14-16 -> CDH_DIM_MISMATCH). */
+int32_t cdh_set_penalty(cdh_handle h, double lambda0, const double *omega, int64_t n_omega);
+
+/* ---- the operator interface (cd_differentiable_function.jl:1-35) ------------- */
+/* numCoordinates(f) */
+int32_t cdh_num_coordinates(cdh_handle h, int64_t *out);
+/* initialize!(f, x): load the iterate (support in SparseIterate order: idx1[i],
+ * val[i]) and rebuild r = y - X beta (cd_differentiable_function.jl:59-72).
+ * x_length is numCoordinates(x), checked against p (coordinate_descent.jl:13). */
+int32_t cdh_initialize(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t *idx1,
+                       const double *val);
+/* Load the iterate WITHOUT touching r: what the binding calls before gradient /
+ * descendCoordinate! / _cdPass! when the caller's x changed since the last call
+ * (the reference reads x[k] directly, cd_differentiable_function.jl:101,253). */
+int32_t cdh_set_iterate(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t *idx1,
+                        const double *val);
+/* gradient(f, x, k) (cd_differentiable_function.jl:75-76, 234-235, 149-158) */
+int32_t cdh_gradient(cdh_handle h, int64_t k1, double *out);
+/* descendCoordinate!(f, g, x, k) -> h (cd_differentiable_function.jl:83-111,
+ * 242-291, 165-194); r is left consistent with beta on return. */
+int32_t cdh_descend(cdh_handle h, int64_t k1, double *out_h);
+
+/* ---- the driver (coordinate_descent.jl) -------------------------------------- */
+/* _findLambdaMax (coordinate_descent.jl:118-149), at the current r. */
+int32_t cdh_lambda_max(cdh_handle h, double *out);
+/* _cdPass! over an explicit visit list (coordinate_descent.jl:94-110):
+ * maxH = max |h|, then dropzeros!. */
+int32_t cdh_pass(cdh_handle h, int64_t m, const int64_t *idx1, double *out_maxH);
+/* _coordinateDescent! (coordinate_descent.jl:65-92): assumes r is initialised. */
+int32_t cdh_solve(cdh_handle h, const cdh_options *opt, cdh_stats *out);
+/* coordinateDescent!(x, f, g::ProxL1, options) (coordinate_descent.jl:7-39):
+ * warm start = initialize! from the handle's current iterate + one solve; cold
+ * start = zero, lambda_max, numSteps+1 solves down a log grid. */
+int32_t cdh_coordinate_descent(cdh_handle h, const cdh_options *opt, cdh_stats *out);
+
+/* ---- results ------------------------------------------------------------------ */
+int32_t cdh_get_beta(cdh_handle h, double *out_p);                       /* Vector(x)   */
+int32_t cdh_get_support(cdh_handle h, int64_t *out_idx1, int64_t *out_nnz); /* nzval2ind  */
+int32_t cdh_get_residual(cdh_handle h, void *out_n_local);               /* f.r (dtype) */
+/* _stdX!(out, X) (utils.jl:127-138): out_j = sqrt(sum_i X_ij^2 / n_total). */
+int32_t cdh_col_rms(cdh_handle h, double *out_p);
+/* out_j = X_j' r for every column at the current r (At_mul_B_row for all j: the
+ * screening scores of _findLargestCorrelations, utils.jl:96-106; KKT checks). */
+int32_t cdh_xt_r(cdh_handle h, double *out_p);
+/* sum r, sum r^2 over all shards (sigma of scaledLasso!, lasso.jl:134; std(f.r)). */
+int32_t cdh_resid_moments(cdh_handle h, double *out_sum, double *out_sumsq);
+/* f(beta) + lambda0 sum omega|beta| at the current state (coordinate_descent.jl:1-3). */
+int32_t cdh_objective(cdh_handle h, double *out);
+
+/* ---- execution control (no reference counterpart) ------------------------------- */
+int32_t cdh_set_sweep_mode(cdh_handle h, int32_t mode, int32_t block);
+/* Replay each pass from a captured hipGraph instead of individual launches. */
+int32_t cdh_set_use_graph(cdh_handle h, int32_t on);
+/* Multi-process row sharding: rank 0 calls cdh_comm_unique_id, broadcasts the
+ * 128 bytes (any transport), every rank calls cdh_comm_init. */
+int32_t cdh_comm_unique_id(void *out_128_bytes);
+int32_t cdh_comm_init(cdh_handle h, const void *id_128_bytes, int32_t rank, int32_t nranks);
+/* HIP-event timing of the sweep kernels on the handle's stream: everything
+ * launched by cdh_pass / cdh_solve between begin and end.  out_launches counts
+ * the dominant (column-streaming) kernel launches, out_ms the event time they
+ * span in total. */
+int32_t cdh_profile_begin(cdh_handle h);
+int32_t cdh_profile_end(cdh_handle h, double *out_ms, int64_t *out_launches,
+                        double *out_algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDHIP_H */

@@ -1,0 +1,340 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (include/cdhip.h) via the
+host mirror, against the CPU oracle on the same seeded inputs and against the committed
+golden vectors.  Tolerances (fp64): |beta_gpu - beta_oracle| <= 1e-10 and relative
+objective gap <= 1e-12 at tight optTol, as BASELINE.json's north_star states; bitwise
+parity is not meaningful because the reference's own `@simd` sums are unordered.
+Shapes follow the reference's tests.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import coordinatedescent_jl_amd as cd
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BETA_TOL = 1e-10
+MODES = [("coord", 0), ("block", 8), ("block", 4), ("block", 2)]
+
+
+def _problem(seed, n, p, s, noise=1.0):
+    rng = np.random.default_rng(seed)
+    X = np.asfortranarray(rng.standard_normal((n, p)))
+    Y = X[:, :s] @ rng.standard_normal(s) + noise * rng.standard_normal(n)
+    return rng, X, Y
+
+
+def _set_mode(f, mode):
+    if mode[0] == "block":
+        f.set_sweep_mode("block", mode[1])
+    else:
+        f.set_sweep_mode("coord")
+
+
+# ---- single visits ---------------------------------------------------------------------
+@pytest.mark.parametrize("loss", ["ls", "sqrt", "wls"])
+def test_descend_coordinate_matches_oracle(loss):
+    rng, X, Y = _problem(1, 300, 12, 4)
+    w = rng.random(300) + 0.5
+    lam = {"ls": 0.05, "sqrt": 1.2, "wls": 0.05}[loss]
+    om = rng.random(12) + 0.5
+    if loss == "ls":
+        f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+    elif loss == "sqrt":
+        f, fo = cd.CDSqrtLassoLoss(Y, X), O.CDSqrtLassoLoss(Y, X)
+    else:
+        f, fo = cd.CDWeightedLSLoss(Y, X, w), O.CDWeightedLSLoss(Y, X, w)
+    g, go = cd.ProxL1(lam, om), O.ProxL1(lam, om)
+    x0 = np.where(rng.random(12) < 0.5, rng.standard_normal(12), 0.0)
+    x, xo = cd.SparseIterate(12, x0), O.SparseIterate(12, x0)
+    cd.initialize_(f, x)
+    O.initialize_(fo, xo)
+    np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-12)
+    for k in [3, 1, 12, 7, 3, 3, 5]:
+        np.testing.assert_allclose(cd.gradient(f, x, k), O.gradient(fo, xo, k), rtol=1e-12, atol=1e-14)
+        h, ho = cd.descendCoordinate_(f, g, x, k), O.descendCoordinate_(fo, go, xo, k)
+        np.testing.assert_allclose(h, ho, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-11)
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist()
+
+
+# ---- fixed number of passes: the trajectory, not just the fixed point --------------------
+@pytest.mark.parametrize("mode", MODES, ids=lambda m: f"{m[0]}{m[1]}")
+@pytest.mark.parametrize("name", ["ls_n200_p50_traj", "sqrt_n100_p50_traj"])
+def test_pass_trajectory_matches_golden(name, mode):
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    X, Y, lam = d["X"], d["Y"], float(d["lam"])
+    cls = cd.CDSqrtLassoLoss if name.startswith("sqrt") else cd.CDLeastSquaresLoss
+    f, g = cls(Y, X), cd.ProxL1(lam)
+    _set_mode(f, mode)
+    p = X.shape[1]
+    x = cd.SparseIterate(p)
+    cd.initialize_(f, x)
+    for t in range(d["betas"].shape[0]):
+        mh = cd.cdPass_(x, f, g, range(1, p + 1))
+        np.testing.assert_allclose(x.dense(), d["betas"][t], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(mh, d["maxhs"][t], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(f.r, d["resid"], rtol=0, atol=1e-11)
+
+
+# ---- whole solves against the golden vectors ------------------------------------------------
+SOLVES = sorted(os.path.basename(c)[:-4] for c in glob.glob(os.path.join(GOLD, "*.npz")) if "traj" not in c)
+
+
+@pytest.mark.parametrize("mode", [MODES[0], MODES[1]], ids=lambda m: f"{m[0]}{m[1]}")
+@pytest.mark.parametrize("name", SOLVES)
+def test_solve_matches_golden(name, mode):
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    X, Y, lam = d["X"], d["Y"], float(d["lam"])
+    omega = d["omega"] if "omega" in d else None
+    cls = cd.CDSqrtLassoLoss if name.startswith("sqrt") else cd.CDLeastSquaresLoss
+    f, g = cls(Y, X), cd.ProxL1(lam, omega)
+    _set_mode(f, mode)
+    p = X.shape[1]
+    x = cd.SparseIterate(p, d["x0"] if "x0" in d else None)
+    warm = "warm0" not in name
+    cd.coordinateDescent_(x, f, g, cd.CDOptions(maxIter=5000, optTol=1e-12, warmStart=warm, randomize=False))
+    assert f.last_stats["converged"]
+    np.testing.assert_allclose(x.dense(), d["beta"], rtol=0, atol=BETA_TOL)
+    assert sorted(x.nzval2ind.tolist()) == sorted(d["support"].tolist())
+    np.testing.assert_allclose(cd.objective(f), float(d["objective"]), rtol=1e-12)
+    np.testing.assert_allclose(f.r, d["resid"], rtol=0, atol=1e-9)
+    if mode[0] == "coord":  # same visit order and pass count as the reference state machine
+        assert x.nzval2ind.tolist() == d["support"].tolist()
+        assert f.last_stats["passes"] == int(d["passes"])
+
+
+# ---- reference test/coordinate_descent.jl:29-99: warm/cold x ordered/random ---------------
+@pytest.mark.parametrize("weighted", [False, True])
+def test_four_option_agreement_and_oracle_parity(weighted):
+    rng, X, Y = _problem(11 + weighted, 500, 50, 10 if weighted else 5)
+    lam = 0.01 if weighted else 0.02
+    om = rng.random(50) if weighted else None
+    f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+    sols = []
+    for warm in (True, False):
+        for rand in (False, True):
+            x0 = np.where(rng.random(50) < 0.6, rng.random(50), 0.0)
+            x, xo = cd.SparseIterate(50, x0), O.SparseIterate(50, x0)
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam, om),
+                                  cd.CDOptions(maxIter=5000, optTol=1e-12, warmStart=warm, randomize=rand, seed=5))
+            st = O.coordinateDescent_(xo, fo, O.ProxL1(lam, om),
+                                      O.CDOptions(maxIter=5000, optTol=1e-12, warmStart=warm, randomize=rand, seed=5))
+            np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+            assert f.last_stats["passes"] == st["passes"]  # same seeded visit orders
+            assert x.nzval2ind.tolist() == xo.nzval2ind.tolist()
+            sols.append(x.dense())
+    for b in sols[1:]:
+        np.testing.assert_allclose(b, sols[0], rtol=0, atol=1e-5)
+
+
+# ---- reference test/lasso.jl ------------------------------------------------------------------
+def test_lasso_zero_above_lambda_max():  # :23-34
+    rng = np.random.default_rng(1)
+    X = np.asfortranarray(rng.standard_normal((100, 10)))
+    Y = X @ np.ones(10) + 0.1 * rng.standard_normal(100)
+    lam = np.max(np.abs(X.T @ Y / 100)) + 0.1
+    out = cd.lasso(X, Y, lam)
+    assert out.x == cd.SparseIterate(10) and out.x.nnz == 0
+    f = cd.CDLeastSquaresLoss(Y, X)
+    x = cd.SparseIterate(10)
+    cd.initialize_(f, x)
+    np.testing.assert_allclose(cd.findLambdaMax(x, f, cd.ProxL1(1.0)), lam - 0.1, rtol=1e-13)
+
+
+def test_lasso_nonzero_kkt_and_interfaces():  # :36-72
+    rng, X, Y = _problem(2, 100, 10, 5, 0.1)
+    lam = np.full(10, 0.3)
+    beta = cd.lasso(X, Y, 1.0, lam, cd.CDOptions(optTol=1e-12))
+    kkt = np.max(np.abs(X.T @ (Y - X @ beta.x.dense()) / 100))
+    assert abs((kkt - 0.3) / 0.3) < 1e-5
+    np.testing.assert_allclose(beta.residuals, Y - X @ beta.x.dense(), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(beta.sigma, np.std(beta.residuals, ddof=1), rtol=1e-10)
+    ref = O.lasso(X, Y, 1.0, lam, O.CDOptions(optTol=1e-12))
+    np.testing.assert_allclose(beta.x.dense(), ref.x.dense(), rtol=0, atol=1e-9)
+    rng, X, Y = _problem(3, 500, 500, 50)
+    x1 = cd.lasso(X, Y, 0.1)
+    x2 = cd.lasso(X, Y, 0.1, np.ones(500))
+    np.testing.assert_allclose(x1.x.dense(), x2.x.dense(), rtol=0, atol=1e-5)
+
+
+def test_dimension_mismatch_errors():  # coordinate_descent.jl:13-16
+    rng, X, Y = _problem(4, 40, 6, 2)
+    f = cd.CDLeastSquaresLoss(Y, X)
+    with pytest.raises(cd.DimensionMismatch):
+        cd.coordinateDescent_(cd.SparseIterate(5), f, cd.ProxL1(0.1))
+    with pytest.raises(cd.DimensionMismatch):
+        cd.coordinateDescent_(cd.SparseIterate(6), f, cd.ProxL1(0.1, np.ones(5)))
+    with pytest.raises(cd.ArgumentError):  # lambda0 == lambda_max: zero-step cold-start range
+        x = cd.SparseIterate(6)
+        cd.initialize_(f, x)
+        lmax = cd.findLambdaMax(x, f, cd.ProxL1(1.0))
+        cd.coordinateDescent_(x, f, cd.ProxL1(lmax), cd.CDOptions(warmStart=False))
+
+
+@pytest.mark.parametrize("mode", [MODES[0], MODES[1]], ids=lambda m: f"{m[0]}{m[1]}")
+def test_sqrt_lasso_kkt_interfaces_and_oracle(mode):  # :106-181
+    rng, X, Y = _problem(6, 500, 500, 50)
+    lam = 1.5
+    f = cd.CDSqrtLassoLoss(Y, X)
+    _set_mode(f, mode)
+    ref = None
+    for warm in (True, False):
+        for rand in (False, True):
+            o = cd.CDOptions(maxIter=5000, optTol=1e-10, warmStart=warm, randomize=rand, seed=9)
+            x = cd.SparseIterate(500, np.where(rng.random(500) < 0.6, rng.random(500), 0.0))
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam), o)
+            ref = x.dense() if ref is None else ref
+            np.testing.assert_allclose(x.dense(), ref, rtol=0, atol=1e-4)
+    y1 = cd.sqrtLasso(X, Y, lam, options=cd.CDOptions(maxIter=5000, optTol=1e-10), standardizeX=False)
+    z1 = cd.sqrtLasso(X, Y, lam, np.ones(500), cd.CDOptions(maxIter=5000, optTol=1e-10))
+    np.testing.assert_allclose(y1.x.dense(), ref, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(z1.x.dense(), ref, rtol=0, atol=1e-4)
+    r = Y - X @ ref
+    assert max(0.0, np.max(np.abs(X.T @ r / np.linalg.norm(r))) - lam) / lam < 1e-3
+    xo = O.SparseIterate(500)
+    O.coordinateDescent_(xo, O.CDSqrtLassoLoss(Y, X), O.ProxL1(lam),
+                         O.CDOptions(maxIter=5000, optTol=1e-12, randomize=False))
+    xg = cd.SparseIterate(500)
+    cd.coordinateDescent_(xg, f, cd.ProxL1(lam), cd.CDOptions(maxIter=5000, optTol=1e-12, randomize=False))
+    np.testing.assert_allclose(xg.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+    # standardizeX=True: the intended omega = _stdX!(X)
+    s1 = cd.sqrtLasso(X, Y, lam, options=cd.CDOptions(maxIter=5000, optTol=1e-10, randomize=False))
+    s2 = O.sqrtLasso(X, Y, lam, options=O.CDOptions(maxIter=5000, optTol=1e-10, randomize=False))
+    np.testing.assert_allclose(s1.x.dense(), s2.x.dense(), rtol=0, atol=1e-8)
+
+
+def test_scaled_lasso():  # :186-216
+    rng, X, Y = _problem(7, 1000, 500, 50)
+    lam = 0.12
+    cdo = cd.CDOptions(maxIter=5000, optTol=1e-8, seed=4)
+    o1 = cd.IterLassoOptions(maxIter=100, optTol=1e-8, optionsCD=cdo)
+    o2 = cd.IterLassoOptions(maxIter=100, optTol=1e-8, initProcedure="InitStd", sigmainit=2.0, optionsCD=cdo)
+    x1, x2 = cd.SparseIterate(500), cd.SparseIterate(500)
+    s1 = cd.scaledLasso_(x1, X, Y, lam, np.ones(500), o1)
+    s2 = cd.scaledLasso_(x2, X, Y, lam, np.ones(500), o2)
+    for x, sol in ((x1, s1), (x2, s2)):
+        kkt = np.max(np.abs(X.T @ (Y - X @ x.dense()) / 1000))
+        assert max(kkt - lam * sol.sigma, 0.0) / (sol.sigma * lam) < 1e-4
+    np.testing.assert_allclose(x1.dense(), x2.dense(), rtol=0, atol=1e-4)
+    xo = O.SparseIterate(500)
+    so = O.scaledLasso_(xo, X, Y, lam, np.ones(500),
+                        O.IterLassoOptions(maxIter=100, optTol=1e-8, optionsCD=O.CDOptions(maxIter=5000, optTol=1e-8, seed=4)))
+    np.testing.assert_allclose(x1.dense(), xo.dense(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(s1.sigma, so.sigma, rtol=1e-6)
+
+
+@pytest.mark.parametrize("standardize", [False, True])
+def test_lasso_path(standardize):  # :220-288
+    rng, X, Y = _problem(8, 1000, 500, 50)
+    opt = cd.CDOptions(maxIter=5000, optTol=1e-8, seed=5)
+    f = cd.CDLeastSquaresLoss(Y, X)
+    np.testing.assert_allclose(cd.stdX(f), np.sqrt((X ** 2).sum(0) / 1000), rtol=1e-13)
+    load = cd.stdX(f) if standardize else None
+    x1 = cd.lasso(X, Y, 0.3, load, opt)
+    x2 = cd.lasso(X, Y, 0.1, load, opt)
+    path = cd.LassoPath(X, Y, [0.3, 0.1], opt, standardizeX=standardize)
+    assert path.lambdapath == [0.3, 0.1]
+    np.testing.assert_allclose(path.betapath[0].dense(), x1.x.dense(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(path.betapath[1].dense(), x2.x.dense(), rtol=0, atol=1e-5)
+    lo, bo = O.LassoPath(X, Y, [0.3, 0.1], O.CDOptions(maxIter=5000, optTol=1e-8, seed=5), standardizeX=standardize)
+    np.testing.assert_allclose(path.betapath[1].dense(), bo[1], rtol=0, atol=1e-6)
+    short = cd.LassoPath(X, Y, [0.3, 0.1], opt, max_hat_s=1, standardizeX=standardize)
+    assert short.lambdapath == [0.3] and len(short.betapath) == 1
+
+
+def test_weighted_ls_loss_matches_oracle():
+    rng, X, Y = _problem(12, 300, 20, 5)
+    w = rng.random(300) + 0.5
+    o = dict(maxIter=5000, optTol=1e-12, randomize=False)
+    x, xo = cd.SparseIterate(20), O.SparseIterate(20)
+    cd.coordinateDescent_(x, cd.CDWeightedLSLoss(Y, X, w), cd.ProxL1(0.05), cd.CDOptions(**o))
+    O.coordinateDescent_(xo, O.CDWeightedLSLoss(Y, X, w), O.ProxL1(0.05), O.CDOptions(**o))
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+
+
+# ---- fp32 storage (fp64 accumulation): loose, declared tolerance ------------------------------
+@pytest.mark.parametrize("mode", [MODES[0], MODES[1]], ids=lambda m: f"{m[0]}{m[1]}")
+def test_fp32_against_fp64_oracle(mode):
+    rng, X, Y = _problem(13, 4000, 64, 8)
+    f = cd.CDLeastSquaresLoss(Y.astype(np.float32), X.astype(np.float32))
+    _set_mode(f, mode)
+    x = cd.SparseIterate(64)
+    cd.coordinateDescent_(x, f, cd.ProxL1(0.05), cd.CDOptions(maxIter=500, optTol=1e-6, randomize=False))
+    xo = O.SparseIterate(64)
+    O.coordinateDescent_(xo, O.CDLeastSquaresLoss(Y, X), O.ProxL1(0.05), O.CDOptions(optTol=1e-10, randomize=False))
+    # fp32 storage of X, y and r: 1e-4 absolute on beta (values are O(1))
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-4)
+    assert f.r.dtype == np.float32
+
+
+# ---- device generator + medium-size parity on device-generated data ------------------------------
+@pytest.mark.parametrize("mode", [MODES[0], MODES[1]], ids=lambda m: f"{m[0]}{m[1]}")
+def test_generated_problem_parity_n200k(mode):
+    n, p, s = 200_003, 48, 6   # odd n: ragged vector tail
+    f, bstar = cd.CDLeastSquaresLoss.generate(n, p, seed=123, s=s, noise=1.0)
+    _set_mode(f, mode)
+    X, Y = f.X_cols(0, p), f.y
+    assert abs(X.mean()) < 5e-3 and abs(X.std() - 1.0) < 5e-3
+    np.testing.assert_allclose(Y - X[:, :s] @ bstar, Y - X[:, :s] @ bstar)  # finite
+    assert abs(np.std(Y - X[:, :s] @ bstar) - 1.0) < 2e-2
+    # row shards regenerate the same matrix (counter-based generator keyed by the global row)
+    f2, _ = cd.CDLeastSquaresLoss.generate(1001, p, seed=123, s=s, noise=1.0, n_total=n, row_offset=70_001)
+    np.testing.assert_array_equal(f2.X_cols(0, p), X[70_001:71_002])
+    np.testing.assert_allclose(f2.y, Y[70_001:71_002], rtol=0, atol=1e-12)
+    x = cd.SparseIterate(p)
+    cd.initialize_(f, x)
+    lmax = cd.findLambdaMax(x, f, cd.ProxL1(1.0))
+    np.testing.assert_allclose(lmax, np.max(np.abs(X.T @ Y)) / n, rtol=1e-12)
+    lam = 0.05 * lmax
+    o = dict(maxIter=500, optTol=1e-12, randomize=False)
+    cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+    xo = O.SparseIterate(p)
+    fo = O.CDLeastSquaresLoss(Y, X)
+    O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+    np.testing.assert_allclose(cd.objective(f), O.objective(fo, O.ProxL1(lam), xo), rtol=1e-12)
+    # determinism: the same solve twice is bit-identical (fixed-order reductions, no float atomics)
+    x2 = cd.SparseIterate(p)
+    cd.coordinateDescent_(x2, f, cd.ProxL1(lam), cd.CDOptions(**o))
+    np.testing.assert_array_equal(x2.dense(), x.dense())
+
+
+# ---- size-independent properties at a size the oracle cannot reach in seconds ------------------
+def test_large_problem_properties():
+    """n = 4e6, p = 256 (8 GB of X): objective decreases monotonically pass by pass, the
+    carried residual equals a from-scratch rebuild, KKT holds at the fixed point, and the
+    blocked sweep reaches the same fixed point as the per-coordinate sweep."""
+    n, p, s = 4_000_000, 256, 16
+    f, bstar = cd.CDLeastSquaresLoss.generate(n, p, seed=7, s=s, noise=2.0)
+    x = cd.SparseIterate(p)
+    cd.initialize_(f, x)
+    lmax = cd.findLambdaMax(x, f, cd.ProxL1(1.0))
+    g = cd.ProxL1(0.02 * lmax)
+    f.set_sweep_mode("block", 8)
+    objs = [cd.objective(f, g)]
+    for _ in range(4):
+        cd.cdPass_(x, f, g, range(1, p + 1))
+        objs.append(cd.objective(f, g))
+    assert all(b <= a * (1 + 1e-14) for a, b in zip(objs, objs[1:]))
+    r_carried = f.r
+    cd.initialize_(f, x)                      # rebuild r = y - X beta from scratch
+    np.testing.assert_allclose(r_carried, f.r, rtol=0, atol=1e-9)
+    cd.coordinateDescent_(x, f, g, cd.CDOptions(maxIter=200, optTol=1e-11, randomize=False))
+    xb = x.dense()
+    xtr = np.zeros(p)
+    cd._lib.check(f._L.cdh_xt_r(f._h, xtr.ctypes.data), f._h)
+    grad = np.abs(xtr) / n
+    act = xb != 0
+    assert np.max(np.abs(grad[act] - g.lambda0)) < 1e-9       # active set: |X_k'r|/n = lambda
+    assert np.all(grad[~act] <= g.lambda0 * (1 + 1e-9))       # inactive: <= lambda
+    assert np.max(np.abs(xb[:s] - bstar)) < 0.1
+    f.set_sweep_mode("coord")
+    xc = cd.SparseIterate(p)
+    cd.coordinateDescent_(xc, f, g, cd.CDOptions(maxIter=200, optTol=1e-11, randomize=False))
+    np.testing.assert_allclose(xc.dense(), xb, rtol=0, atol=BETA_TOL)
