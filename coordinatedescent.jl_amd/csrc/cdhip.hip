@@ -24,7 +24,7 @@ namespace {
 std::string g_create_error;
 
 constexpr int kMaxStepGrid = 2048;   // blocks of k_step (8 per CU on 256 CUs)
-constexpr int kBlockGridPerCU = 3;   // k_blockstep occupancy target (register-bound)
+constexpr int kBlockGridPerCU = 4;   // upper bound of k_blockstep blocks per CU (partials sizing)
 constexpr int kColChunks = 64;       // row chunks per column in k_col_dots
 constexpr int kMaxBlockB = 8;
 
@@ -96,6 +96,7 @@ struct cdh_handle_s {
     bool use_graph = false;
     bool domain_error = false;
     int step_grid = 1, block_grid = 1;
+    bool nt = true;  // non-temporal loads for the X column streams
     // comm
     void* comm = nullptr;
     int rank = 0, nranks = 1;
@@ -224,8 +225,12 @@ template <typename T, int B> void launch_block_chunk(cdh_handle h, int m) {
     int nprev = 0;
     for (int pos0 = 0; pos0 < m; pos0 += B) {
         const int nb = std::min(B, m - pos0);
-        hipLaunchKernelGGL((k_blockstep<T, B>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
-                           h->nvec, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev, h->d_partials);
+        if (h->nt)
+            hipLaunchKernelGGL((k_blockstep<T, B, true>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X,
+                               h->ld, h->nvec, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev, h->d_partials);
+        else
+            hipLaunchKernelGGL((k_blockstep<T, B, false>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X,
+                               h->ld, h->nvec, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev, h->d_partials);
         if (!h->comm) {
             hipLaunchKernelGGL((k_block_finalize<B, true>), dim3(1), dim3(1024), 0, h->stream,
                                h->d_partials, G, nb, h->d_ctrl, h->beta, h->omega, h->d_idx, h->d_hs,
@@ -250,10 +255,13 @@ template <typename T> void launch_coord_chunk(cdh_handle h, int m) {
     const int G = h->step_grid;
     for (int pos = 0; pos < m; ++pos) {
         if (h->has_w)
-            hipLaunchKernelGGL((k_step<T, true>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X,
+            hipLaunchKernelGGL((k_step<T, true, true>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X,
                                h->ld, h->nvec, (const T*)h->w, (T*)h->r, h->d_idx, h->d_hs, pos, h->d_partials);
+        else if (h->nt)
+            hipLaunchKernelGGL((k_step<T, false, true>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X,
+                               h->ld, h->nvec, (const T*)nullptr, (T*)h->r, h->d_idx, h->d_hs, pos, h->d_partials);
         else
-            hipLaunchKernelGGL((k_step<T, false>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X,
+            hipLaunchKernelGGL((k_step<T, false, false>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X,
                                h->ld, h->nvec, (const T*)nullptr, (T*)h->r, h->d_idx, h->d_hs, pos, h->d_partials);
         if (!h->comm) {
             hipLaunchKernelGGL(k_finalize<true>, dim3(1), dim3(kBlock), 0, h->stream, h->d_partials, G,
@@ -451,10 +459,15 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         hipDeviceProp_t prop;
         HIPCHK(h, hipGetDeviceProperties(&prop, device));
         const int cus = std::max(1, prop.multiProcessorCount);
+        // tuning knobs (experiments only; defaults are the measured best)
+        auto env_int = [](const char* nm, int dflt) { const char* v = getenv(nm); return v ? atoi(v) : dflt; };
+        h->nt = env_int("CDH_NT", 1) != 0;
+        const int step_per_cu = std::max(1, env_int("CDH_STEP_GRID_PER_CU", 8));
+        const int block_per_cu = std::max(1, std::min(kBlockGridPerCU, env_int("CDH_BLOCK_GRID_PER_CU", 3)));
         const int64_t want = (h->nvec + (int64_t)kBlock * kUnroll - 1) / ((int64_t)kBlock * kUnroll);
-        h->step_grid = (int)std::max<int64_t>(1, std::min<int64_t>({want, (int64_t)kMaxStepGrid, (int64_t)cus * 8}));
+        h->step_grid = (int)std::max<int64_t>(1, std::min<int64_t>({want, (int64_t)kMaxStepGrid, (int64_t)cus * step_per_cu}));
         const int64_t wantb = (h->nvec + kBlock - 1) / kBlock;
-        h->block_grid = (int)std::max<int64_t>(1, std::min<int64_t>(wantb, (int64_t)cus * kBlockGridPerCU));
+        h->block_grid = (int)std::max<int64_t>(1, std::min<int64_t>(wantb, (int64_t)cus * block_per_cu));
         const size_t colbytes = (size_t)h->ld * h->esz;
         HIPCHK(h, hipMalloc(&h->X, colbytes * (size_t)p));
         HIPCHK(h, hipMalloc(&h->y, colbytes));

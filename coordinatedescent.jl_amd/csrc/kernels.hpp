@@ -38,12 +38,23 @@ struct Ctrl {
     int32_t pad;
 };
 
+// 16-byte native vectors (clang ext_vector_type: element access v[e] stays in registers and
+// __builtin_nontemporal_load accepts them).
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+typedef float fvec4 __attribute__((ext_vector_type(4)));
 template <typename T> struct VecOf;
-template <> struct VecOf<double> { using V = double2; static constexpr int N = 2; };
-template <> struct VecOf<float>  { using V = float4;  static constexpr int N = 4; };
+template <> struct VecOf<double> { using V = dvec2; static constexpr int N = 2; };
+template <> struct VecOf<float>  { using V = fvec4; static constexpr int N = 4; };
 
-__device__ __forceinline__ double2 vzero(double2*) { return make_double2(0.0, 0.0); }
-__device__ __forceinline__ float4 vzero(float4*) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ dvec2 vzero(dvec2*) { return dvec2{0.0, 0.0}; }
+__device__ __forceinline__ fvec4 vzero(fvec4*) { return fvec4{0.f, 0.f, 0.f, 0.f}; }
+
+// X columns are streamed once per launch: a non-temporal load keeps them from evicting the
+// residual vector (read AND written by every launch) out of L2 / Infinity Cache.
+template <bool NT, typename V> __device__ __forceinline__ V ld_stream(const V* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
 
 // r <- r - h*xp ; (a,b,q) += (xc.xc, xc.r, r.r)   [optionally weighted by w]
 __device__ __forceinline__ void visit_elem(double xc, double& r, double xp, double h, bool apply,
@@ -59,21 +70,23 @@ __device__ __forceinline__ void visit_elem(double xc, double& r, double xp, doub
     }
     q = fma(r, r, q);
 }
-__device__ __forceinline__ void visit_vec(const double2& xc, double2& r, const double2& xp, double h,
-                                          bool apply, const double2& w, bool hasw, double& a,
+__device__ __forceinline__ void visit_vec(const dvec2& xc, dvec2& r, const dvec2& xp, double h,
+                                          bool apply, const dvec2& w, bool hasw, double& a,
                                           double& b, double& q) {
-    visit_elem(xc.x, r.x, xp.x, h, apply, w.x, hasw, a, b, q);
-    visit_elem(xc.y, r.y, xp.y, h, apply, w.y, hasw, a, b, q);
+    double r0 = r.x, r1 = r.y;
+    visit_elem(xc.x, r0, xp.x, h, apply, w.x, hasw, a, b, q);
+    visit_elem(xc.y, r1, xp.y, h, apply, w.y, hasw, a, b, q);
+    r = dvec2{r0, r1};
 }
-__device__ __forceinline__ void visit_vec(const float4& xc, float4& r, const float4& xp, double h,
-                                          bool apply, const float4& w, bool hasw, double& a,
+__device__ __forceinline__ void visit_vec(const fvec4& xc, fvec4& r, const fvec4& xp, double h,
+                                          bool apply, const fvec4& w, bool hasw, double& a,
                                           double& b, double& q) {
     double r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
     visit_elem(xc.x, r0, xp.x, h, apply, w.x, hasw, a, b, q);
     visit_elem(xc.y, r1, xp.y, h, apply, w.y, hasw, a, b, q);
     visit_elem(xc.z, r2, xp.z, h, apply, w.z, hasw, a, b, q);
     visit_elem(xc.w, r3, xp.w, h, apply, w.w, hasw, a, b, q);
-    r = make_float4((float)r0, (float)r1, (float)r2, (float)r3);
+    r = fvec4{(float)r0, (float)r1, (float)r2, (float)r3};
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -108,6 +121,32 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [NV * 
     }
 }
 
+// Sum NV per-thread values over the block and store them VALUE-MAJOR: out[v * G + block]
+// (so the one-block finalize kernels read each value's G partials as one coalesced run).
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double* lds /* [NV * 4] */,
+                                                double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = wave_sum(v[i]);
+        if (lane == 0) lds[i * (kBlock / 64) + wid] = v[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += kBlock) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) s += lds[i * (kBlock / 64) + w];
+        out[(int64_t)i * gridDim.x + blockIdx.x] = s;
+    }
+}
+// One wave sums G partials of one value: lanes stride the run, fixed order.
+__device__ __forceinline__ double wave_sum_run(const double* __restrict__ run, int G, int lane) {
+    double s = 0.0;
+    for (int i = lane; i < G; i += 64) s += run[i];
+    return wave_sum(s);
+}
+
 // ---------------------------------------------------------------------------------
 // k_step: visit number `pos` of a pass.  Applies the pending residual update of visit
 // pos-1 (r -= hs[pos-1] * X[:, idx[pos-1]], skipped when that h is 0 or pos == 0) and,
@@ -115,7 +154,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [NV * 
 //   a = sum w x^2, b = sum w x r, q = sum r^2     (w = 1 unless HASW)
 // One partial record per block.  Streams: X_k (+X_prev) read, r read (+written).
 // ---------------------------------------------------------------------------------
-template <typename T, bool HASW>
+template <typename T, bool HASW, bool NT>
 __global__ __launch_bounds__(kBlock) void k_step(const T* __restrict__ X, int64_t ld, int64_t nvec,
                                                  const T* __restrict__ w, T* __restrict__ r,
                                                  const int64_t* __restrict__ idx,
@@ -143,9 +182,9 @@ __global__ __launch_bounds__(kBlock) void k_step(const T* __restrict__ X, int64_
             const int64_t j = base + (int64_t)u * kBlock;
             xc[u] = vzero((V*)nullptr); rr[u] = xc[u]; xp[u] = xc[u]; ww[u] = xc[u];
             if (j < nvec) {
-                xc[u] = cv[j];
+                xc[u] = ld_stream<NT>(cv + j);
                 rr[u] = rv[j];
-                if (apply) xp[u] = pv[j];
+                if (apply) xp[u] = ld_stream<NT>(pv + j);
                 if (HASW) ww[u] = wv[j];
             }
         }
@@ -156,11 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const T* __restrict__ X, int64_
             if (apply && j < nvec) rv[j] = rr[u];
         }
     }
-    block_sum<3>(acc, lds);
-    if (threadIdx.x == 0) {
-        double* out = partials + (int64_t)blockIdx.x * kNSum;
-        out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
-    }
+    block_sum_store<3>(acc, lds, partials);
 }
 
 // r -= h * X[:, k] for the last visit of a pass (or of a chunk): pos = number of visits done.
@@ -205,48 +240,56 @@ __global__ __launch_bounds__(kBlock) void k_axpy(const T* __restrict__ X, int64_
 __device__ __forceinline__ double soft_threshold(double v, double t) {
     return v > t ? v - t : (v < -t ? v + t : 0.0);
 }
-__device__ inline void scalar_update(double a, double b, double q, Ctrl* ctrl, double* beta,
-                                     const double* omega, int64_t k, int pos, double* hs,
-                                     double* newval, int32_t* touched) {
-    const double om = ctrl->has_omega ? omega[k] : 1.0;
-    const double oldv = beta[k];
-    double nv;
-    int32_t tch = 0;
-    if (ctrl->loss == 1 /* CDH_SQRT */) {
-        const double lam = ctrl->lambda0 * om;
+// Pure function: (sums, old value, weight) -> (new value, pre-prox-non-zero flag, domain flag).
+struct VisitOut { double nv; int32_t tch; int32_t dom; };
+__device__ __forceinline__ VisitOut visit_update(int loss, double lambda0, double n_total, double a,
+                                                 double b, double q, double oldv, double om) {
+    VisitOut o{0.0, 0, 0};
+    if (loss == 1 /* CDH_SQRT */) {
+        const double lam = lambda0 * om;
         const double s = fma(oldv, a, b);
         double rsqr = q + 2.0 * oldv * b + oldv * oldv * a;
         if (rsqr < 0.0) rsqr = 0.0;
         if (fabs(s) <= lam * sqrt(rsqr)) {
-            nv = 0.0;
+            o.nv = 0.0;
         } else {
             double u = 1.0 - lam * lam / a;
             double v = rsqr - s * s / a;
             // Julia throws DomainError on sqrt of a negative; flag it when it is clearly
             // negative, clamp rounding-level negatives (this formulation gets rsqr from an
             // identity and carries a little more cancellation noise than the reference).
-            if (u <= 0.0 || v < -1e-12 * rsqr) ctrl->domain_error = 1;
+            if (u <= 0.0 || v < -1e-12 * rsqr) o.dom = 1;
             if (v < 0.0) v = 0.0;
             if (u <= 0.0) u = 1e-300;
             const double c = lam / sqrt(u) * sqrt(v);
-            nv = (s > 0.0 ? (s - c) : (s + c)) / a;
+            o.nv = (s > 0.0 ? (s - c) : (s + c)) / a;
         }
     } else {
         const double v = oldv + b / a;
-        tch = (v != 0.0) ? 1 : 0;
-        nv = soft_threshold(v, ctrl->lambda0 * om * (ctrl->n_total / a));
+        o.tch = (v != 0.0) ? 1 : 0;
+        o.nv = soft_threshold(v, lambda0 * om * (n_total / a));
     }
-    const double h = nv - oldv;
-    beta[k] = nv;
+    return o;
+}
+__device__ inline void scalar_update(double a, double b, double q, Ctrl* ctrl, double* beta,
+                                     const double* omega, int64_t k, int pos, double* hs,
+                                     double* newval, int32_t* touched) {
+    const double om = ctrl->has_omega ? omega[k] : 1.0;
+    const double oldv = beta[k];
+    const VisitOut o = visit_update(ctrl->loss, ctrl->lambda0, ctrl->n_total, a, b, q, oldv, om);
+    if (o.dom) ctrl->domain_error = 1;
+    const double h = o.nv - oldv;
+    beta[k] = o.nv;
     hs[pos] = h;
-    newval[pos] = nv;
-    touched[pos] = tch;
+    newval[pos] = o.nv;
+    touched[pos] = o.tch;
     const double ah = fabs(h);
     if (ah > ctrl->maxH || ah != ah) ctrl->maxH = ah;  // NaN sticks
 }
 
-// Sum the per-block partial records in a fixed order.  FUSED: also do the scalar
-// update (single process).  Otherwise write (a, b, q) to `red` for the all-reduce.
+// Sum the per-block partials (value-major, G per value) in a fixed order: wave v sums
+// value v.  FUSED: also do the scalar update (single process).  Otherwise write (a, b, q)
+// to `red` for the all-reduce.
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_finalize(const double* __restrict__ partials, int nparts,
                                                      Ctrl* ctrl, double* beta,
@@ -254,19 +297,32 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const double* __restrict__ 
                                                      const int64_t* __restrict__ idx, double* hs,
                                                      double* newval, int32_t* touched, int pos,
                                                      double* red) {
-    __shared__ double lds[3 * (kBlock / 64)];
-    double acc[3] = {0.0, 0.0, 0.0};
-    for (int i = threadIdx.x; i < nparts; i += kBlock) {
-        const double* pr = partials + (int64_t)i * kNSum;
-        acc[0] += pr[0]; acc[1] += pr[1]; acc[2] += pr[2];
+    __shared__ double sums[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // issue the scalar operands' loads before the reduction so their latency overlaps it
+    int64_t k = 0;
+    double oldv = 0.0, om = 1.0;
+    if (FUSED && threadIdx.x == 0) {
+        k = idx[pos];
+        oldv = beta[k];
+        if (ctrl->has_omega) om = omega[k];
     }
-    block_sum<3>(acc, lds);
+    if (wid < 3) {
+        const double s = wave_sum_run(partials + (int64_t)wid * nparts, nparts, lane);
+        if (lane == 0) sums[wid] = s;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         if (FUSED) {
-            scalar_update(acc[0], acc[1], acc[2], ctrl, beta, omega, idx[pos], pos, hs, newval,
-                          touched);
+            const VisitOut o = visit_update(ctrl->loss, ctrl->lambda0, ctrl->n_total, sums[0], sums[1],
+                                            sums[2], oldv, om);
+            if (o.dom) ctrl->domain_error = 1;
+            const double h = o.nv - oldv;
+            beta[k] = o.nv; hs[pos] = h; newval[pos] = o.nv; touched[pos] = o.tch;
+            const double ah = fabs(h);
+            if (ah > ctrl->maxH || ah != ah) ctrl->maxH = ah;
         } else {
-            red[0] = acc[0]; red[1] = acc[1]; red[2] = acc[2]; red[3] = 0.0;
+            red[0] = sums[0]; red[1] = sums[1]; red[2] = sums[2]; red[3] = 0.0;
         }
     }
 }
@@ -292,7 +348,7 @@ template <int B> struct BlockRec {
     static constexpr int N = NG + B + 1;  // G (upper, row-major), c, q
 };
 
-template <typename T, int B>
+template <typename T, int B, bool NT>
 __global__ __launch_bounds__(kBlock) void k_blockstep(const T* __restrict__ X, int64_t ld,
                                                       int64_t nvec, T* __restrict__ r,
                                                       const int64_t* __restrict__ idx,
@@ -330,35 +386,30 @@ __global__ __launch_bounds__(kBlock) void k_blockstep(const T* __restrict__ X, i
         V rr = rv[j];
         V xc[B];
 #pragma unroll
-        for (int i = 0; i < B; ++i) xc[i] = (i < nb) ? cv[i][j] : vzero((V*)nullptr);
+        for (int i = 0; i < B; ++i) xc[i] = (i < nb) ? ld_stream<NT>(cv[i] + j) : vzero((V*)nullptr);
         double re[NV];
-        {
-            const T* rp = reinterpret_cast<const T*>(&rr);
 #pragma unroll
-            for (int e = 0; e < NV; ++e) re[e] = (double)rp[e];
-        }
+        for (int e = 0; e < NV; ++e) re[e] = (double)rr[e];
         if (any) {
 #pragma unroll
             for (int i = 0; i < B; ++i) {
                 if (hp[i] != 0.0) {
-                    V xp = pv[i][j];
-                    const T* xpp = reinterpret_cast<const T*>(&xp);
+                    const V xp = ld_stream<NT>(pv[i] + j);
 #pragma unroll
-                    for (int e = 0; e < NV; ++e) re[e] = fma(-hp[i], (double)xpp[e], re[e]);
+                    for (int e = 0; e < NV; ++e) re[e] = fma(-hp[i], (double)xp[e], re[e]);
                 }
             }
-            T* rp = reinterpret_cast<T*>(&rr);
 #pragma unroll
-            for (int e = 0; e < NV; ++e) rp[e] = (T)re[e];
+            for (int e = 0; e < NV; ++e) rr[e] = (T)re[e];
             rv[j] = rr;
 #pragma unroll
-            for (int e = 0; e < NV; ++e) re[e] = (double)rp[e];  // what is stored is what is used
+            for (int e = 0; e < NV; ++e) re[e] = (double)rr[e];  // what is stored is what is used
         }
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             double xe[B];
 #pragma unroll
-            for (int i = 0; i < B; ++i) xe[i] = (double)reinterpret_cast<const T*>(&xc[i])[e];
+            for (int i = 0; i < B; ++i) xe[i] = (double)xc[i][e];
             int g = 0;
 #pragma unroll
             for (int i = 0; i < B; ++i) {
@@ -371,12 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_blockstep(const T* __restrict__ X, i
             acc[NREC - 1] = fma(re[e], re[e], acc[NREC - 1]);
         }
     }
-    block_sum<NREC>(acc, lds);
-    if (threadIdx.x == 0) {
-        double* out = partials + (int64_t)blockIdx.x * NREC;
-#pragma unroll
-        for (int i = 0; i < NREC; ++i) out[i] = acc[i];
-    }
+    block_sum_store<NREC>(acc, lds, partials);
 }
 
 // Rank-(<=B) residual update for the last block of a pass: r -= sum_i hs[pos0+i] X[:, idx[pos0+i]]
@@ -406,20 +452,18 @@ __global__ __launch_bounds__(kBlock) void k_block_axpy(const T* __restrict__ X, 
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nvec; j += stride) {
         V rr = rv[j];
         double re[NV];
-        T* rp = reinterpret_cast<T*>(&rr);
 #pragma unroll
-        for (int e = 0; e < NV; ++e) re[e] = (double)rp[e];
+        for (int e = 0; e < NV; ++e) re[e] = (double)rr[e];
 #pragma unroll
         for (int i = 0; i < B; ++i) {
             if (hp[i] != 0.0) {
-                V xp = pv[i][j];
-                const T* xpp = reinterpret_cast<const T*>(&xp);
+                const V xp = ld_stream<true>(pv[i] + j);
 #pragma unroll
-                for (int e = 0; e < NV; ++e) re[e] = fma(-hp[i], (double)xpp[e], re[e]);
+                for (int e = 0; e < NV; ++e) re[e] = fma(-hp[i], (double)xp[e], re[e]);
             }
         }
 #pragma unroll
-        for (int e = 0; e < NV; ++e) rp[e] = (T)re[e];
+        for (int e = 0; e < NV; ++e) rr[e] = (T)re[e];
         rv[j] = rr;
     }
 }
@@ -429,22 +473,69 @@ __global__ __launch_bounds__(kBlock) void k_block_axpy(const T* __restrict__ X, 
 //   b_i = c_i - sum_{j<i} h_j G_ji
 //   q_i = q_{i-1} - 2 h_{i-1} b_{i-1} + h_{i-1}^2 G_{i-1,i-1}
 // where b_{i-1} is taken before the update (X_c(i-1) . r_{i-1}).
+// Runs in ONE wave: lanes 0..nb-1 fetch idx / beta / omega in parallel (no dependent
+// global-load chain inside the recurrence), lane 0 runs the recurrence on registers
+// exchanged through LDS, lanes 0..nb-1 write the results back.
 template <int B>
-__device__ inline void block_scalar_updates(const double* rec, int nb, Ctrl* ctrl, double* beta,
-                                            const double* omega, const int64_t* idx, int pos0,
-                                            double* hs, double* newval, int32_t* touched) {
+__device__ inline void block_scalar_updates(const double* rec /* LDS or global */, int nb, Ctrl* ctrl,
+                                            double* beta, const double* omega, const int64_t* idx,
+                                            int pos0, double* hs, double* newval, int32_t* touched,
+                                            double* sh /* LDS: [4 * B] doubles + [2 * B] ints */) {
     constexpr int NG = BlockRec<B>::NG;
-    double hloc[B];
-    double q = rec[NG + B];
-    for (int i = 0; i < nb; ++i) {
-        // G index of (j, i), j <= i, row-major upper: off(j) + (i - j), off(j) = j*B - j(j-1)/2
-        double b = rec[NG + i];
-        for (int j = 0; j < i; ++j) b = fma(-hloc[j], rec[j * B - j * (j - 1) / 2 + (i - j)], b);
-        const double a = rec[i * B - i * (i - 1) / 2];
-        scalar_update(a, b, q, ctrl, beta, omega, idx[pos0 + i], pos0 + i, hs, newval, touched);
-        hloc[i] = hs[pos0 + i];
-        q = q - 2.0 * hloc[i] * b + hloc[i] * hloc[i] * a;
-        if (q < 0.0) q = 0.0;
+    const int lane = threadIdx.x & 63;
+    double* s_old = sh;            // [B]
+    double* s_om = sh + B;         // [B]
+    double* s_nv = sh + 2 * B;     // [B]
+    double* s_h = sh + 3 * B;      // [B]
+    int64_t* s_k = reinterpret_cast<int64_t*>(sh + 4 * B);       // [B]
+    int32_t* s_t = reinterpret_cast<int32_t*>(sh + 5 * B);       // [B]
+    const int has_omega = ctrl->has_omega;
+    if (lane < nb) {
+        const int64_t k = idx[pos0 + lane];
+        s_k[lane] = k;
+        s_old[lane] = beta[k];
+        s_om[lane] = has_omega ? omega[k] : 1.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) {
+        const int loss = ctrl->loss;
+        const double lambda0 = ctrl->lambda0, n_total = ctrl->n_total;
+        double maxH = ctrl->maxH;
+        int dom = 0;
+        double q = rec[NG + B];
+        for (int i = 0; i < nb; ++i) {
+            // G index of (j, i), j <= i, row-major upper: off(j) + (i - j), off(j) = j*B - j(j-1)/2
+            double b = rec[NG + i];
+            for (int j = 0; j < i; ++j) b = fma(-s_h[j], rec[j * B - j * (j - 1) / 2 + (i - j)], b);
+            const double a = rec[i * B - i * (i - 1) / 2];
+            double oldv = s_old[i];
+            for (int j = 0; j < i; ++j)            // the same coordinate earlier in this block
+                if (s_k[j] == s_k[i]) oldv = s_nv[j];
+            const VisitOut o = visit_update(loss, lambda0, n_total, a, b, q, oldv, s_om[i]);
+            dom |= o.dom;
+            const double h = o.nv - oldv;
+            s_nv[i] = o.nv; s_h[i] = h; s_t[i] = o.tch;
+            const double ah = fabs(h);
+            if (ah > maxH || ah != ah) maxH = ah;
+            q = q - 2.0 * h * b + h * h * a;
+            if (q < 0.0) q = 0.0;
+        }
+        ctrl->maxH = maxH;
+        if (dom) ctrl->domain_error = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < nb) {
+        hs[pos0 + lane] = s_h[lane];
+        newval[pos0 + lane] = s_nv[lane];
+        touched[pos0 + lane] = s_t[lane];
+        // last writer of a repeated coordinate wins, as sequential visits would have it
+        bool last = true;
+        for (int j = lane + 1; j < nb; ++j) last = last && (s_k[j] != s_k[lane]);
+        if (last) beta[s_k[lane]] = s_nv[lane];
     }
 }
 
@@ -458,28 +549,34 @@ __global__ __launch_bounds__(1024) void k_block_finalize(const double* __restric
                                                          double* red) {
     constexpr int NREC = BlockRec<B>::N;
     __shared__ double rec[NREC];
+    __shared__ double sh[6 * B];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;  // 16 waves
     for (int v = wid; v < NREC; v += 16) {
-        double s = 0.0;
-        for (int i = lane; i < nparts; i += 64) s += partials[(int64_t)i * NREC + v];
-        s = wave_sum(s);
+        const double s = wave_sum_run(partials + (int64_t)v * nparts, nparts, lane);
         if (lane == 0) rec[v] = s;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (wid == 0) {
         if (FUSED) {
-            block_scalar_updates<B>(rec, nb, ctrl, beta, omega, idx, pos0, hs, newval, touched);
+            block_scalar_updates<B>(rec, nb, ctrl, beta, omega, idx, pos0, hs, newval, touched, sh);
         } else {
-            for (int v = 0; v < NREC; ++v) red[v] = rec[v];
+            for (int v = lane; v < NREC; v += 64) red[v] = rec[v];
         }
     }
 }
 template <int B>
-__global__ void k_block_scalar(const double* __restrict__ red, int nb, Ctrl* ctrl, double* beta,
-                               const double* __restrict__ omega, const int64_t* __restrict__ idx,
-                               double* hs, double* newval, int32_t* touched, int pos0) {
-    if (threadIdx.x == 0 && blockIdx.x == 0)
-        block_scalar_updates<B>(red, nb, ctrl, beta, omega, idx, pos0, hs, newval, touched);
+__global__ __launch_bounds__(64) void k_block_scalar(const double* __restrict__ red, int nb, Ctrl* ctrl,
+                                                     double* beta, const double* __restrict__ omega,
+                                                     const int64_t* __restrict__ idx, double* hs,
+                                                     double* newval, int32_t* touched, int pos0) {
+    constexpr int NREC = BlockRec<B>::N;
+    __shared__ double rec[NREC];
+    __shared__ double sh[6 * B];
+    for (int v = threadIdx.x; v < NREC; v += 64) rec[v] = red[v];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    block_scalar_updates<B>(rec, nb, ctrl, beta, omega, idx, pos0, hs, newval, touched, sh);
 }
 
 // ---------------------------------------------------------------------------------
@@ -596,23 +693,17 @@ __global__ __launch_bounds__(kBlock) void k_resid_moments(int64_t nvec, const T*
             acc[2] = fma(w ? (double)wp[e] * re : re, re, acc[2]);
         }
     }
-    block_sum<3>(acc, lds);
-    if (threadIdx.x == 0) {
-        double* out = partials + (int64_t)blockIdx.x * kNSum;
-        out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
-    }
+    block_sum_store<3>(acc, lds, partials);
 }
-// sum the (block, 4) records -> red[0..2]
+// sum the value-major partials -> red[0..2]
 __global__ __launch_bounds__(kBlock) void k_sum_records(const double* __restrict__ partials,
                                                         int nparts, double* red) {
-    __shared__ double lds[3 * (kBlock / 64)];
-    double acc[3] = {0.0, 0.0, 0.0};
-    for (int i = threadIdx.x; i < nparts; i += kBlock) {
-        const double* pr = partials + (int64_t)i * kNSum;
-        acc[0] += pr[0]; acc[1] += pr[1]; acc[2] += pr[2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (wid < 3) {
+        const double s = wave_sum_run(partials + (int64_t)wid * nparts, nparts, lane);
+        if (lane == 0) red[wid] = s;
     }
-    block_sum<3>(acc, lds);
-    if (threadIdx.x == 0) { red[0] = acc[0]; red[1] = acc[1]; red[2] = acc[2]; red[3] = 0.0; }
+    if (threadIdx.x == 0) red[3] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------
