@@ -76,9 +76,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=10_000_000)
-    ap.add_argument("--p", type=int, default=1000)
-    ap.add_argument("--s", type=int, default=100)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--cols", type=int, default=1000)
+    ap.add_argument("--planted", type=int, default=100)
     ap.add_argument("--noise", type=float, default=6.0)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default=os.environ.get("CDH_BENCH_MODE", "block"), choices=["coord", "block"])
@@ -94,22 +94,22 @@ def main():
 
     cp = sharded.ControlPlane()
     assert cp.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={cp.world}"
-    row0, n_local = sharded.shard_rows(a.n, cp.rank, cp.world)
+    row0, n_local = sharded.shard_rows(a.rows, cp.rank, cp.world)
     dtype = np.float64 if a.dtype == "f64" else np.float32
     L = cd._lib.lib()
     ndev = cd._lib.C.c_int32()
     L.cdh_device_count(cd._lib.C.byref(ndev))
     device = cp.local_rank % max(ndev.value, 1)
 
-    f, bstar = cd.CDLeastSquaresLoss.generate(n_local, a.p, seed=123, s=a.s, noise=a.noise, dtype=dtype,
-                                              device=device, n_total=a.n, row_offset=row0)
+    f, bstar = cd.CDLeastSquaresLoss.generate(n_local, a.cols, seed=123, s=a.planted, noise=a.noise, dtype=dtype,
+                                              device=device, n_total=a.rows, row_offset=row0)
     sharded.connect(f, cp)
     f.set_sweep_mode(a.mode, a.block)
-    x = cd.SparseIterate(a.p)
+    x = cd.SparseIterate(a.cols)
     cd.initialize_(f, x)
     lmax = cd.findLambdaMax(x, f, cd.ProxL1(1.0))
     g = cd.ProxL1(a.lam_frac * lmax)
-    visit = list(range(1, a.p + 1))
+    visit = list(range(1, a.cols + 1))
 
     def step():
         # one step = initialize!(f, 0) (beta = 0, r = y) + one full cyclic pass from there:
@@ -133,7 +133,7 @@ def main():
     dt = cp.max_over_ranks(time.perf_counter() - t0)
     ev_ms, launches, alg_bytes = f.profile_end()
 
-    updates = a.steps * a.p
+    updates = a.steps * a.cols
     value = updates / dt
     esz = np.dtype(dtype).itemsize
     # roofline of the dominant (column-streaming) kernel, per launch, this rank's shard
@@ -145,8 +145,8 @@ def main():
         "n_gpus": cp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype,
         "data": "synthetic",
-        "config": {"workload": f"lasso_full_cyclic_sweep_gaussian_n{a.n}_p{a.p}_{a.dtype}_allmove",
-                   "n": a.n, "p": a.p, "s": a.s, "noise": a.noise, "lambda_over_lambda_max": a.lam_frac,
+        "config": {"workload": f"lasso_full_cyclic_sweep_gaussian_n{a.rows}_p{a.cols}_{a.dtype}_allmove",
+                   "n": a.rows, "p": a.cols, "s": a.planted, "noise": a.noise, "lambda_over_lambda_max": a.lam_frac,
                    "sweep_mode": a.mode + (str(a.block) if a.mode == "block" else ""),
                    "parallelism": f"rows{cp.world}", "moved_per_sweep": int(x.nnz), "last_maxH": maxh},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
