@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--noise", type=float, default=6.0)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default=os.environ.get("CDH_BENCH_MODE", "block"), choices=["coord", "block"])
-    ap.add_argument("--block", type=int, default=8)
+    ap.add_argument("--block", type=int, default=8, choices=[2, 4, 8, 16, 32])
     ap.add_argument("--lam-frac", type=float, default=1e-6, help="lambda / lambda_max")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()

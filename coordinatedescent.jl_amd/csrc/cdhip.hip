@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "gram_kernels.hpp"
 #include "sparse_iterate.hpp"
 
 using namespace cdk;
@@ -95,7 +96,7 @@ struct cdh_handle_s {
     int mode = CDH_SWEEP_COORD, blockB = 8;
     bool use_graph = false;
     bool domain_error = false;
-    int step_grid = 1, block_grid = 1;
+    int step_grid = 1, block_grid = 1, gram_grid = 1, cus = 1, gram32_per_cu = 1;
     bool nt = true;  // non-temporal loads for the X column streams
     // comm
     void* comm = nullptr;
@@ -251,6 +252,34 @@ template <typename T, int B> void launch_block_chunk(cdh_handle h, int m) {
                        h->nvec, (T*)h->r, h->d_idx, h->d_hs, last0, m - last0);
 }
 
+// wide blocks (B = 16 / 32): MFMA-accumulated Gram kernel + two-stage reduction
+template <typename T, int NG> void launch_gram_chunk(cdh_handle h, int m) {
+    using R = GramRec<NG>;
+    constexpr int B = R::B;
+    // blocks per CU follow the kernel's register footprint (2 waves per SIMD for both widths)
+    const int G = std::max(1, NG == 2 ? std::min(h->gram_grid, h->cus * h->gram32_per_cu) : h->gram_grid);
+    int nprev = 0;
+    for (int pos0 = 0; pos0 < m; pos0 += B) {
+        const int nb = std::min(B, m - pos0);
+        if (h->nt)
+            hipLaunchKernelGGL((k_gramstep<T, NG, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
+                               (const T*)h->X, h->ld, h->nvec, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
+                               h->d_partials);
+        else
+            hipLaunchKernelGGL((k_gramstep<T, NG, false>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
+                               (const T*)h->X, h->ld, h->nvec, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
+                               h->d_partials);
+        hipLaunchKernelGGL(k_gram_reduce, dim3(64), dim3(256), 0, h->stream, h->d_partials, G, R::N, h->d_red);
+        allreduce(h, h->d_red, R::N);
+        hipLaunchKernelGGL((k_gram_scalar<NG>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb, h->d_ctrl,
+                           h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos0);
+        nprev = nb;
+    }
+    const int last0 = ((m - 1) / B) * B;
+    hipLaunchKernelGGL(k_multi_axpy<T>, dim3(h->step_grid), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
+                       h->nvec, (T*)h->r, h->d_idx, h->d_hs, last0, m - last0);
+}
+
 template <typename T> void launch_coord_chunk(cdh_handle h, int m) {
     const int G = h->step_grid;
     for (int pos = 0; pos < m; ++pos) {
@@ -291,6 +320,8 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     CHK(dispatch(h, [&](auto* t) {
         using T = std::remove_pointer_t<decltype(t)>;
         if (!blocked) launch_coord_chunk<T>(h, m);
+        else if (h->blockB == 32) launch_gram_chunk<T, 2>(h, m);
+        else if (h->blockB == 16) launch_gram_chunk<T, 1>(h, m);
         else if (h->blockB == 8) launch_block_chunk<T, 8>(h, m);
         else if (h->blockB == 4) launch_block_chunk<T, 4>(h, m);
         else launch_block_chunk<T, 2>(h, m);
@@ -468,6 +499,10 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->step_grid = (int)std::max<int64_t>(1, std::min<int64_t>({want, (int64_t)kMaxStepGrid, (int64_t)cus * step_per_cu}));
         const int64_t wantb = (h->nvec + kBlock - 1) / kBlock;
         h->block_grid = (int)std::max<int64_t>(1, std::min<int64_t>(wantb, (int64_t)cus * block_per_cu));
+        h->cus = cus;
+        h->gram32_per_cu = std::max(1, env_int("CDH_GRAM32_GRID_PER_CU", 2));
+        const int64_t wantg = (h->nvec + 64 * kGramWaves - 1) / (64 * kGramWaves);
+        h->gram_grid = (int)std::max<int64_t>(1, std::min<int64_t>(wantg, (int64_t)cus * std::max(1, env_int("CDH_GRAM_GRID_PER_CU", 2))));
         const size_t colbytes = (size_t)h->ld * h->esz;
         HIPCHK(h, hipMalloc(&h->X, colbytes * (size_t)p));
         HIPCHK(h, hipMalloc(&h->y, colbytes));
@@ -488,9 +523,10 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         HIPCHK(h, hipMalloc(&h->d_touched, sizeof(int32_t) * h->cap));
         h->partials_doubles = std::max<size_t>({(size_t)kMaxStepGrid * kNSum,
                                                 (size_t)cus * kBlockGridPerCU * BlockRec<kMaxBlockB>::N,
-                                                (size_t)4096 * kColChunks * 2});
+                                                (size_t)4096 * kColChunks * 2,
+                                                (size_t)cus * 4 * GramRec<2>::N});
         HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * h->partials_doubles));
-        HIPCHK(h, hipMalloc(&h->d_red, sizeof(double) * 64));
+        HIPCHK(h, hipMalloc(&h->d_red, sizeof(double) * 1024));
         HIPCHK(h, hipMalloc(&h->d_colout, sizeof(double) * 2 * p));
         HIPCHK(h, hipMalloc(&h->d_sup_idx, sizeof(int64_t) * p));
         HIPCHK(h, hipMalloc(&h->d_sup_val, sizeof(double) * p));
@@ -825,8 +861,8 @@ int32_t cdh_objective(cdh_handle h, double* out) {
 
 int32_t cdh_set_sweep_mode(cdh_handle h, int32_t mode, int32_t block) {
     if (mode != CDH_SWEEP_COORD && mode != CDH_SWEEP_BLOCK) return fail(h, CDH_BAD_ARG, "unknown sweep mode");
-    if (mode == CDH_SWEEP_BLOCK && block != 2 && block != 4 && block != 8)
-        return fail(h, CDH_BAD_ARG, "block size must be 2, 4 or 8");
+    if (mode == CDH_SWEEP_BLOCK && block != 2 && block != 4 && block != 8 && block != 16 && block != 32)
+        return fail(h, CDH_BAD_ARG, "block size must be 2, 4, 8, 16 or 32");
     h->mode = mode;
     if (mode == CDH_SWEEP_BLOCK) h->blockB = block;
     return CDH_OK;

@@ -1,0 +1,309 @@
+// gram_kernels.hpp -- wide-block (B = 16 or 32 visits per launch) variant of the blocked sweep.
+//
+// Same arithmetic as k_blockstep (kernels.hpp): one pass over r applies the previous block's
+// rank-B residual update (cd_differentiable_function.jl:107-109 for B visits) and accumulates
+// c = X_B' r, the Gram block G = X_B' X_B and q = r'r for the block's columns (:94-99 for B
+// visits); the B scalar updates (:101-104 / :271-283) then run on (c, G, q).
+//
+// Why a second kernel: with B = 16/32 the B(B+1)/2 per-lane accumulators of the vector-ALU
+// formulation no longer fit the register file (153 / 561 fp64 values).  The accumulation is
+// moved to the matrix pipe, used here as a register-cheap ACCUMULATOR, not as a throughput
+// device: v_mfma_f64_16x16x4_f64 keeps a whole 16x16 fp64 tile in 8 VGPRs, exact fp64 FMA
+// chains, and on CDNA4 has the same flop rate as the vector ALU.  The kernel stays HBM-bound:
+// B = 32 streams 66 vectors per launch and needs ~40 % of the fp64 matrix rate at HBM speed.
+// Bytes per visit fall to (2B+2)/B = 2.06 vectors (B = 32) and exchanges per sweep to p/32.
+//
+// Lane mapping of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md section 3): lane l supplies
+// A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; D[i = (l>>4) + 4 t][j = l&15] sits in
+// register t.  For G_IJ = X_I' X_J the K dimension is the ROW index, and any assignment of rows
+// to K-slices is valid (it is a sum over all rows), so lane (c = l&15, g = l>>4) simply loads
+// 16 bytes of column c at vector index 4u + g: one wave instruction fetches 64 contiguous bytes
+// from each of 16 columns, and A == B for the diagonal tile.  X' r uses the same A with
+// B = r broadcast over j (every column of D then holds c).
+#pragma once
+#include "kernels.hpp"
+
+namespace cdk {
+
+typedef double dvec4 __attribute__((ext_vector_type(4)));
+
+template <int NG> struct GramRec {
+    static constexpr int B = 16 * NG;
+    static constexpr int NT = NG * (NG + 1) / 2;      // tiles (0,0) [(0,1) (1,1)]
+    static constexpr int OFF_C = NT * 256;
+    static constexpr int OFF_Q = OFF_C + B;
+    static constexpr int N = OFF_Q + 1;
+    // record offset of G[s][j], s <= j (positions inside the block)
+    __host__ __device__ static constexpr int g(int s, int j) {
+        const int gs = s >> 4, gj = j >> 4;
+        const int tile = (gs == 0) ? gj : 2;
+        return tile * 256 + (s & 15) * 16 + (j & 15);
+    }
+};
+
+constexpr int kGramWaves = 4;  // waves per block
+
+template <typename T, int NG, bool NT_>
+__global__ __launch_bounds__(64 * kGramWaves) void k_gramstep(
+    const T* __restrict__ X, int64_t ld, int64_t nvec, T* __restrict__ r,
+    const int64_t* __restrict__ idx, const double* __restrict__ hs, int pos0, int nb, int nprev,
+    double* __restrict__ partials) {
+    using V = typename VecOf<T>::V;
+    constexpr int NV = VecOf<T>::N;
+    using R = GramRec<NG>;
+    constexpr int B = R::B;
+    __shared__ V s_r[kGramWaves][64];            // r' of the wave's current 64-vector chunk
+    __shared__ double s_hp[B];
+    __shared__ int64_t s_kp[B];
+    __shared__ double s_red[kGramWaves][R::N];   // end-of-kernel cross-wave reduction
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+
+    // previous block's updates, compacted to those with h != 0 (no per-column branches in the
+    // streaming loop: conditional loads would be waited for one by one)
+    __shared__ int s_nzp;
+    if (threadIdx.x == 0) {
+        int m = 0;
+        for (int i = 0; i < nprev; ++i) {
+            const double h = hs[pos0 - nprev + i];
+            if (h != 0.0) { s_hp[m] = h; s_kp[m] = idx[pos0 - nprev + i]; ++m; }
+        }
+        s_nzp = m;
+    }
+    __syncthreads();
+    const int nzp = s_nzp;
+    const bool anyp = nzp > 0;
+
+    // this lane's column in each 16-column group (columns beyond nb contribute zeros)
+    const V* cv[NG];
+    bool act[NG];
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+        const int i = 16 * grp + c;
+        act[grp] = i < nb;
+        cv[grp] = reinterpret_cast<const V*>(X + idx[pos0 + (act[grp] ? i : 0)] * ld);
+    }
+    V* __restrict__ rv = reinterpret_cast<V*>(r);
+
+    dvec4 tile[R::NT], ctile[NG];
+#pragma unroll
+    for (int t = 0; t < R::NT; ++t) tile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NG; ++t) ctile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
+    double qacc = 0.0;
+
+    const int64_t nchunks = (nvec + 63) >> 6;
+    for (int64_t ch = (int64_t)blockIdx.x * kGramWaves + wave; ch < nchunks;
+         ch += (int64_t)gridDim.x * kGramWaves) {
+        const int64_t v0 = ch << 6;
+        // ---- phase A (coalesced): r' = r - sum_i h_i X_prev,i on this wave's 64 vectors -------
+        const int64_t jv = v0 + lane;
+        const bool inb = jv < nvec;
+        V rr = inb ? rv[jv] : vzero((V*)nullptr);
+        if (anyp) {
+            double re[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) re[e] = (double)rr[e];
+            for (int i0 = 0; i0 < nzp; i0 += 8) {     // 8 independent loads in flight per group
+                V xp[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int ii = (i0 + t < nzp) ? i0 + t : nzp - 1;
+                    xp[t] = inb ? ld_stream<NT_>(reinterpret_cast<const V*>(X + s_kp[ii] * ld) + jv)
+                                : vzero((V*)nullptr);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const double h = (i0 + t < nzp) ? s_hp[i0 + t] : 0.0;
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) re[e] = fma(-h, (double)xp[t][e], re[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NV; ++e) rr[e] = (T)re[e];
+            if (inb) rv[jv] = rr;
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) qacc = fma((double)rr[e], (double)rr[e], qacc);
+        __builtin_amdgcn_wave_barrier();
+        s_r[wave][lane] = rr;
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase B: tiles += X_I' X_J, X_I' r' over the chunk's rows, in UH-sized groups of
+        // fragment loads (NG = 2 takes two halves so the kernel fits 2 waves per SIMD: the other
+        // wave's loads then overlap this wave's MFMA phase) ------------------------------------
+        constexpr int UH = (NG == 2) ? 8 : 16;
+#pragma unroll
+        for (int u0 = 0; u0 < 16; u0 += UH) {
+            V xf[UH][NG];
+#pragma unroll
+            for (int u = 0; u < UH; ++u) {
+                const int64_t v = v0 + 4 * (u0 + u) + g;
+#pragma unroll
+                for (int grp = 0; grp < NG; ++grp)
+                    xf[u][grp] = (act[grp] && v < nvec) ? ld_stream<NT_>(cv[grp] + v) : vzero((V*)nullptr);
+            }
+#pragma unroll
+            for (int u = 0; u < UH; ++u) {
+                const V rf = s_r[wave][4 * (u0 + u) + g];
+#pragma unroll
+                for (int e = 0; e < NV; ++e) {
+                    const double a0 = (double)xf[u][0][e];
+                    const double rb = (double)rf[e];
+                    tile[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, tile[0], 0, 0, 0);
+                    ctile[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, rb, ctile[0], 0, 0, 0);
+                    if constexpr (NG == 2) {
+                        const double a1 = (double)xf[u][1][e];
+                        tile[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, tile[1], 0, 0, 0);
+                        tile[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, tile[2], 0, 0, 0);
+                        ctile[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, rb, ctile[1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- per-wave record -> LDS -> sum over the block's waves -> value-major partials ----------
+    qacc = wave_sum(qacc);
+#pragma unroll
+    for (int t = 0; t < R::NT; ++t)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) s_red[wave][t * 256 + (g + 4 * q4) * 16 + c] = tile[t][q4];
+    if (c == 0) {
+#pragma unroll
+        for (int t = 0; t < NG; ++t)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) s_red[wave][R::OFF_C + 16 * t + g + 4 * q4] = ctile[t][q4];
+    }
+    if (lane == 0) s_red[wave][R::OFF_Q] = qacc;
+    __syncthreads();
+    for (int v = threadIdx.x; v < R::N; v += blockDim.x) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kGramWaves; ++w) s += s_red[w][v];
+        partials[(int64_t)v * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// Stage 1 of the reduction: wave (block*4 + w) sums the runs of values v, v + nwaves, ...
+__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ partials, int nparts,
+                                                     int nvals, double* __restrict__ rec) {
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nvals; v += nw) {
+        const double s = wave_sum_run(partials + (int64_t)v * nparts, nparts, lane);
+        if (lane == 0) rec[v] = s;
+    }
+}
+
+// Stage 2: the B sequential scalar updates, one wave, lane i owns visit i of the block:
+//   b_i = c_i - sum_{s<i} h_s G_si is kept current by a lane-parallel rank-1 update after each
+//   visit; q_s = q_{s-1} - 2 h_{s-1} b_{s-1} + h_{s-1}^2 a_{s-1}  (kernels.hpp, same identities).
+template <int NG>
+__global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ rec_g, int nb, Ctrl* ctrl,
+                                                    double* beta, const double* __restrict__ omega,
+                                                    const int64_t* __restrict__ idx, double* hs,
+                                                    double* newval, int32_t* touched, int pos0) {
+    using R = GramRec<NG>;
+    __shared__ double rec[R::N];
+    const int lane = threadIdx.x;
+    for (int v = lane; v < R::N; v += 64) rec[v] = rec_g[v];
+    __builtin_amdgcn_wave_barrier();
+    const bool mine = lane < nb;
+    const int li = mine ? lane : 0;
+    const int64_t k_me = idx[pos0 + li];
+    double old_me = beta[k_me];
+    const double om_me = ctrl->has_omega ? omega[k_me] : 1.0;
+    double b_me = rec[R::OFF_C + li];
+    const double a_me = rec[R::g(li, li)];
+    double q = rec[R::OFF_Q];
+    const int loss = ctrl->loss;
+    const double lambda0 = ctrl->lambda0, n_total = ctrl->n_total;
+    double maxH = ctrl->maxH;
+    int dom = 0;
+    double nv_me = 0.0, h_me = 0.0;
+    int32_t t_me = 0;
+    for (int s = 0; s < nb; ++s) {
+        const VisitOut o = visit_update(loss, lambda0, n_total, a_me, b_me, q, old_me, om_me);
+        const double h_cand = o.nv - old_me;
+        const double h_s = __shfl(h_cand, s, 64);
+        const double nv_s = __shfl(o.nv, s, 64);
+        const double b_s = __shfl(b_me, s, 64);
+        const double a_s = __shfl(a_me, s, 64);
+        const int64_t k_s = __shfl(k_me, s, 64);
+        dom |= __shfl(o.dom, s, 64);
+        if (lane == s) { nv_me = o.nv; h_me = h_cand; t_me = o.tch; }
+        if (mine && lane > s) {
+            b_me = fma(-h_s, rec[R::g(s, lane)], b_me);
+            if (k_me == k_s) old_me = nv_s;          // the same coordinate later in this block
+        }
+        const double ah = fabs(h_s);
+        if (ah > maxH || ah != ah) maxH = ah;
+        q = q - 2.0 * h_s * b_s + h_s * h_s * a_s;
+        if (q < 0.0) q = 0.0;
+    }
+    if (lane == 0) { ctrl->maxH = maxH; if (dom) ctrl->domain_error = 1; }
+    bool last = true;                                // last writer of a repeated coordinate wins
+    for (int j = 1; j < nb; ++j) {
+        const int64_t k_j = __shfl(k_me, j, 64);
+        if (j > lane && k_j == k_me) last = false;
+    }
+    if (mine) {
+        hs[pos0 + lane] = h_me;
+        newval[pos0 + lane] = nv_me;
+        touched[pos0 + lane] = t_me;
+        if (last) beta[k_me] = nv_me;
+    }
+}
+
+// r -= sum_i hs[pos0+i] X[:, idx[pos0+i]], i < nprev: the trailing update of a pass (any width)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_multi_axpy(const T* __restrict__ X, int64_t ld,
+                                                       int64_t nvec, T* __restrict__ r,
+                                                       const int64_t* __restrict__ idx,
+                                                       const double* __restrict__ hs, int pos0,
+                                                       int nprev) {
+    using V = typename VecOf<T>::V;
+    constexpr int NV = VecOf<T>::N;
+    __shared__ double s_hp[64];
+    __shared__ int64_t s_kp[64];
+    __shared__ int s_nzp;
+    if (threadIdx.x == 0) {
+        int m = 0;
+        for (int i = 0; i < nprev && i < 64; ++i) {
+            const double h = hs[pos0 + i];
+            if (h != 0.0) { s_hp[m] = h; s_kp[m] = idx[pos0 + i]; ++m; }
+        }
+        s_nzp = m;
+    }
+    __syncthreads();
+    const int nzp = s_nzp;
+    if (nzp == 0) return;
+    V* __restrict__ rv = reinterpret_cast<V*>(r);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nvec; j += stride) {
+        V rr = rv[j];
+        double re[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) re[e] = (double)rr[e];
+        for (int i0 = 0; i0 < nzp; i0 += 8) {
+            V xp[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int ii = (i0 + t < nzp) ? i0 + t : nzp - 1;
+                xp[t] = ld_stream<true>(reinterpret_cast<const V*>(X + s_kp[ii] * ld) + j);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const double h = (i0 + t < nzp) ? s_hp[i0 + t] : 0.0;
+#pragma unroll
+                for (int e = 0; e < NV; ++e) re[e] = fma(-h, (double)xp[t][e], re[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) rr[e] = (T)re[e];
+        rv[j] = rr;
+    }
+}
+
+}  // namespace cdk
