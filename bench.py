@@ -82,7 +82,10 @@ def main():
     ap.add_argument("--noise", type=float, default=6.0)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default=os.environ.get("CDH_BENCH_MODE", "block"), choices=["coord", "block"])
-    ap.add_argument("--block", type=int, default=8, choices=[2, 4, 8, 16, 32])
+    ap.add_argument("--block", type=int, default=None, choices=[2, 4, 8, 16, 32],
+                    help="visits per launch of the blocked sweep (default 16 on one GPU, 32 sharded: "
+                         "half the exchanges per sweep)")
+    ap.add_argument("--graph", action="store_true", help="replay each pass from a captured hipGraph")
     ap.add_argument("--lam-frac", type=float, default=1e-6, help="lambda / lambda_max")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -104,7 +107,10 @@ def main():
     f, bstar = cd.CDLeastSquaresLoss.generate(n_local, a.cols, seed=123, s=a.planted, noise=a.noise, dtype=dtype,
                                               device=device, n_total=a.rows, row_offset=row0)
     sharded.connect(f, cp)
+    if a.block is None:
+        a.block = 16 if cp.world == 1 else 32
     f.set_sweep_mode(a.mode, a.block)
+    f.set_use_graph(a.graph)
     x = cd.SparseIterate(a.cols)
     cd.initialize_(f, x)
     lmax = cd.findLambdaMax(x, f, cd.ProxL1(1.0))
@@ -139,7 +145,7 @@ def main():
     # roofline of the dominant (column-streaming) kernel, per launch, this rank's shard
     achieved = alg_bytes / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else 0.0
     stream_model = esz * n_local * 5.0 * updates / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else 0.0
-    kernel = "k_blockstep" if a.mode == "block" else "k_step"
+    kernel = ("k_gramstep" if a.block >= 16 else "k_blockstep") if a.mode == "block" else "k_step"
     res = {
         "metric": "coord_updates_per_sec", "value": value, "unit": "coord-updates/s",
         "n_gpus": cp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

@@ -95,6 +95,7 @@ struct cdh_handle_s {
     cdh::SupportList x;
     int mode = CDH_SWEEP_COORD, blockB = 8;
     bool use_graph = false;
+    std::vector<std::pair<uint64_t, hipGraphExec_t>> graphs;  // captured chunk launch sequences
     bool domain_error = false;
     int step_grid = 1, block_grid = 1, gram_grid = 1, cus = 1, gram32_per_cu = 1;
     bool nt = true;  // non-temporal loads for the X column streams
@@ -317,16 +318,44 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     CHK(upload_ctrl(h));
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     const bool blocked = (h->mode == CDH_SWEEP_BLOCK) && !h->has_w;
-    CHK(dispatch(h, [&](auto* t) {
-        using T = std::remove_pointer_t<decltype(t)>;
-        if (!blocked) launch_coord_chunk<T>(h, m);
-        else if (h->blockB == 32) launch_gram_chunk<T, 2>(h, m);
-        else if (h->blockB == 16) launch_gram_chunk<T, 1>(h, m);
-        else if (h->blockB == 8) launch_block_chunk<T, 8>(h, m);
-        else if (h->blockB == 4) launch_block_chunk<T, 4>(h, m);
-        else launch_block_chunk<T, 2>(h, m);
-        return CDH_OK;
-    }));
+    auto enqueue = [&]() {
+        return dispatch(h, [&](auto* t) {
+            using T = std::remove_pointer_t<decltype(t)>;
+            if (!blocked) launch_coord_chunk<T>(h, m);
+            else if (h->blockB == 32) launch_gram_chunk<T, 2>(h, m);
+            else if (h->blockB == 16) launch_gram_chunk<T, 1>(h, m);
+            else if (h->blockB == 8) launch_block_chunk<T, 8>(h, m);
+            else if (h->blockB == 4) launch_block_chunk<T, 4>(h, m);
+            else launch_block_chunk<T, 2>(h, m);
+            return CDH_OK;
+        });
+    };
+    // hipGraph replay: the launch sequence of an m-visit chunk depends only on (m, mode, B) --
+    // every kernel takes its visit position as a literal and reads idx / hs / lambda from device
+    // memory -- so one captured graph serves every later pass of that length.  (Not used with a
+    // communicator: RCCL calls are left out of stream capture.)
+    if (h->use_graph && !h->comm) {
+        const uint64_t key = ((uint64_t)m << 16) | ((uint64_t)(blocked ? h->blockB : 0) << 4) |
+                             (h->has_w ? 2u : 0u) | (h->nt ? 1u : 0u);
+        hipGraphExec_t exec = nullptr;
+        for (auto& e : h->graphs) if (e.first == key) exec = e.second;
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            enqueue();
+            HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
+            HIPCHK(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            HIPCHK(h, hipGraphDestroy(graph));
+            if (h->graphs.size() >= 32) {  // bounded cache: drop the oldest
+                (void)hipGraphExecDestroy(h->graphs.front().second);
+                h->graphs.erase(h->graphs.begin());
+            }
+            h->graphs.emplace_back(key, exec);
+        }
+        HIPCHK(h, hipGraphLaunch(exec, h->stream));
+    } else {
+        CHK(enqueue());
+    }
     HIPCHK(h, hipGetLastError());
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_hs, h->d_hs, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
@@ -434,6 +463,7 @@ void free_all(cdh_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
     void* dev[] = {h->X, h->y, h->r, h->w, h->beta, h->omega, h->d_ctrl, h->d_idx, h->d_hs, h->d_newval,
                    h->d_touched, h->d_partials, h->d_red, h->d_colout, h->d_sup_idx, h->d_sup_val};
     for (void* p : dev) if (p) (void)hipFree(p);

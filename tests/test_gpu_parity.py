@@ -338,3 +338,47 @@ def test_large_problem_properties():
     xc = cd.SparseIterate(p)
     cd.coordinateDescent_(xc, f, g, cd.CDOptions(maxIter=200, optTol=1e-11, randomize=False))
     np.testing.assert_allclose(xc.dense(), xb, rtol=0, atol=BETA_TOL)
+
+
+# ---- hipGraph replay of the pass: same launches, same bits ------------------------------------
+@pytest.mark.parametrize("mode", [MODES[0], MODES[1], MODES[4]], ids=lambda m: f"{m[0]}{m[1]}")
+def test_graph_replay_is_bit_identical(mode):
+    rng, X, Y = _problem(21, 3000, 70, 9)
+    o = cd.CDOptions(maxIter=300, optTol=1e-12, randomize=True, seed=3)
+    res = []
+    for graph in (False, True):
+        f = cd.CDLeastSquaresLoss(Y, X)
+        _set_mode(f, mode)
+        f.set_use_graph(graph)
+        x = cd.SparseIterate(70)
+        cd.coordinateDescent_(x, f, cd.ProxL1(0.05), o)          # full + active passes of many lengths
+        cd.coordinateDescent_(x, f, cd.ProxL1(0.02), o)          # warm start, graphs reused
+        res.append((x.dense(), f.r, f.last_stats["passes"]))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]
+
+
+# ---- edge cases: tiny n, p = 1, partial blocks, repeated coordinates in one pass ----------------
+@pytest.mark.parametrize("mode", MODES, ids=lambda m: f"{m[0]}{m[1]}")
+def test_edge_shapes_and_repeated_coordinates(mode):
+    for (n, p) in [(1, 1), (3, 2), (5, 1), (7, 33), (130, 17)]:
+        rng = np.random.default_rng(100 * n + p)
+        X = np.asfortranarray(rng.standard_normal((n, p)))
+        Y = rng.standard_normal(n)
+        f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+        _set_mode(f, mode)
+        g, go = cd.ProxL1(0.01), O.ProxL1(0.01)
+        x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+        cd.initialize_(f, x)
+        O.initialize_(fo, xo)
+        # a visit list with repeats, longer than p and not a multiple of any block size
+        visit = [int(v) for v in rng.integers(1, p + 1, size=2 * p + 3)]
+        for _ in range(3):
+            mh, mho = cd.cdPass_(x, f, g, visit), O.cdPass_(xo, fo, go, visit)
+            np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-11)
+            np.testing.assert_allclose(mh, mho, rtol=1e-9, atol=1e-13)
+            assert x.nzval2ind.tolist() == xo.nzval2ind.tolist()
+        np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-11)
+    # empty visit list: _cdPass! only runs dropzeros!
+    assert cd.cdPass_(x, f, g, []) == 0.0
