@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--noise", type=float, default=6.0)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default=os.environ.get("CDH_BENCH_MODE", "block"), choices=["coord", "block"])
-    ap.add_argument("--block", type=int, default=None, choices=[2, 4, 8, 16, 32],
+    ap.add_argument("--block", type=int, default=None, choices=[2, 4, 8, 16, 32, 64],
                     help="visits per launch of the blocked sweep (default 16 on one GPU, 32 sharded: "
                          "half the exchanges per sweep)")
     ap.add_argument("--graph", action="store_true", help="replay each pass from a captured hipGraph")

@@ -258,7 +258,7 @@ template <typename T, int NG> void launch_gram_chunk(cdh_handle h, int m) {
     using R = GramRec<NG>;
     constexpr int B = R::B;
     // blocks per CU follow the kernel's register footprint (2 waves per SIMD for both widths)
-    const int G = std::max(1, NG == 2 ? std::min(h->gram_grid, h->cus * h->gram32_per_cu) : h->gram_grid);
+    const int G = std::max(1, NG >= 2 ? std::min(h->gram_grid, h->cus * h->gram32_per_cu) : h->gram_grid);
     int nprev = 0;
     for (int pos0 = 0; pos0 < m; pos0 += B) {
         const int nb = std::min(B, m - pos0);
@@ -270,7 +270,7 @@ template <typename T, int NG> void launch_gram_chunk(cdh_handle h, int m) {
             hipLaunchKernelGGL((k_gramstep<T, NG, false>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
                                (const T*)h->X, h->ld, h->nvec, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
                                h->d_partials);
-        hipLaunchKernelGGL(k_gram_reduce, dim3(64), dim3(256), 0, h->stream, h->d_partials, G, R::N, h->d_red);
+        hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + 3) / 4), dim3(256), 0, h->stream, h->d_partials, G, R::N, h->d_red);  // one value per wave
         allreduce(h, h->d_red, R::N);
         hipLaunchKernelGGL((k_gram_scalar<NG>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb, h->d_ctrl,
                            h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos0);
@@ -322,6 +322,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
         return dispatch(h, [&](auto* t) {
             using T = std::remove_pointer_t<decltype(t)>;
             if (!blocked) launch_coord_chunk<T>(h, m);
+            else if (h->blockB == 64) launch_gram_chunk<T, 4>(h, m);
             else if (h->blockB == 32) launch_gram_chunk<T, 2>(h, m);
             else if (h->blockB == 16) launch_gram_chunk<T, 1>(h, m);
             else if (h->blockB == 8) launch_block_chunk<T, 8>(h, m);
@@ -554,9 +555,9 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->partials_doubles = std::max<size_t>({(size_t)kMaxStepGrid * kNSum,
                                                 (size_t)cus * kBlockGridPerCU * BlockRec<kMaxBlockB>::N,
                                                 (size_t)4096 * kColChunks * 2,
-                                                (size_t)cus * 4 * GramRec<2>::N});
+                                                (size_t)cus * 2 * GramRec<4>::N});
         HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * h->partials_doubles));
-        HIPCHK(h, hipMalloc(&h->d_red, sizeof(double) * 1024));
+        HIPCHK(h, hipMalloc(&h->d_red, sizeof(double) * 4096));
         HIPCHK(h, hipMalloc(&h->d_colout, sizeof(double) * 2 * p));
         HIPCHK(h, hipMalloc(&h->d_sup_idx, sizeof(int64_t) * p));
         HIPCHK(h, hipMalloc(&h->d_sup_val, sizeof(double) * p));
@@ -891,8 +892,8 @@ int32_t cdh_objective(cdh_handle h, double* out) {
 
 int32_t cdh_set_sweep_mode(cdh_handle h, int32_t mode, int32_t block) {
     if (mode != CDH_SWEEP_COORD && mode != CDH_SWEEP_BLOCK) return fail(h, CDH_BAD_ARG, "unknown sweep mode");
-    if (mode == CDH_SWEEP_BLOCK && block != 2 && block != 4 && block != 8 && block != 16 && block != 32)
-        return fail(h, CDH_BAD_ARG, "block size must be 2, 4, 8, 16 or 32");
+    if (mode == CDH_SWEEP_BLOCK && block != 2 && block != 4 && block != 8 && block != 16 && block != 32 && block != 64)
+        return fail(h, CDH_BAD_ARG, "block size must be 2, 4, 8, 16, 32 or 64");
     h->mode = mode;
     if (mode == CDH_SWEEP_BLOCK) h->blockB = block;
     return CDH_OK;

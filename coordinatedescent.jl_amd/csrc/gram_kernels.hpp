@@ -29,22 +29,25 @@ typedef double dvec4 __attribute__((ext_vector_type(4)));
 
 template <int NG> struct GramRec {
     static constexpr int B = 16 * NG;
-    static constexpr int NT = NG * (NG + 1) / 2;      // tiles (0,0) [(0,1) (1,1)]
+    static constexpr int NT = NG * (NG + 1) / 2;      // upper-triangular tiles, row-major
     static constexpr int OFF_C = NT * 256;
     static constexpr int OFF_Q = OFF_C + B;
     static constexpr int N = OFF_Q + 1;
     // record offset of G[s][j], s <= j (positions inside the block)
     __host__ __device__ static constexpr int g(int s, int j) {
         const int gs = s >> 4, gj = j >> 4;
-        const int tile = (gs == 0) ? gj : 2;
-        return tile * 256 + (s & 15) * 16 + (j & 15);
+        return tile(gs, gj) * 256 + (s & 15) * 16 + (j & 15);
+    }
+    // index of tile (gs, gj), gs <= gj
+    __host__ __device__ static constexpr int tile(int gs, int gj) {
+        return gs * NG - gs * (gs - 1) / 2 + (gj - gs);
     }
 };
 
 constexpr int kGramWaves = 4;  // waves per block
 
 template <typename T, int NG, bool NT_>
-__global__ __launch_bounds__(64 * kGramWaves) void k_gramstep(
+__global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
     const T* __restrict__ X, int64_t ld, int64_t nvec, T* __restrict__ r,
     const int64_t* __restrict__ idx, const double* __restrict__ hs, int pos0, int nb, int nprev,
     double* __restrict__ partials) {
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(64 * kGramWaves) void k_gramstep(
     __shared__ V s_r[kGramWaves][64];            // r' of the wave's current 64-vector chunk
     __shared__ double s_hp[B];
     __shared__ int64_t s_kp[B];
-    __shared__ double s_red[kGramWaves][R::N];   // end-of-kernel cross-wave reduction
+    __shared__ double s_red[kGramWaves][256];    // end-of-kernel cross-wave reduction, per tile
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
 
@@ -104,16 +107,17 @@ __global__ __launch_bounds__(64 * kGramWaves) void k_gramstep(
             double re[NV];
 #pragma unroll
             for (int e = 0; e < NV; ++e) re[e] = (double)rr[e];
-            for (int i0 = 0; i0 < nzp; i0 += 8) {     // 8 independent loads in flight per group
-                V xp[8];
+            constexpr int PG = (NG == 4) ? 4 : 8;      // independent loads in flight per group
+            for (int i0 = 0; i0 < nzp; i0 += PG) {
+                V xp[PG];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
+                for (int t = 0; t < PG; ++t) {
                     const int ii = (i0 + t < nzp) ? i0 + t : nzp - 1;
                     xp[t] = inb ? ld_stream<NT_>(reinterpret_cast<const V*>(X + s_kp[ii] * ld) + jv)
                                 : vzero((V*)nullptr);
                 }
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
+                for (int t = 0; t < PG; ++t) {
                     const double h = (i0 + t < nzp) ? s_hp[i0 + t] : 0.0;
 #pragma unroll
                     for (int e = 0; e < NV; ++e) re[e] = fma(-h, (double)xp[t][e], re[e]);
@@ -129,9 +133,9 @@ __global__ __launch_bounds__(64 * kGramWaves) void k_gramstep(
         s_r[wave][lane] = rr;
         __builtin_amdgcn_wave_barrier();
         // ---- phase B: tiles += X_I' X_J, X_I' r' over the chunk's rows, in UH-sized groups of
-        // fragment loads (NG = 2 takes two halves so the kernel fits 2 waves per SIMD: the other
-        // wave's loads then overlap this wave's MFMA phase) ------------------------------------
-        constexpr int UH = (NG == 2) ? 8 : 16;
+        // fragment loads (16/NG vector rows at a time so the kernel fits 2 waves per SIMD: the
+        // other wave's loads then overlap this wave's MFMA phase) ------------------------------------
+        constexpr int UH = (NG == 4) ? 2 : 16 / NG;
 #pragma unroll
         for (int u0 = 0; u0 < 16; u0 += UH) {
             V xf[UH][NG];
@@ -147,15 +151,17 @@ __global__ __launch_bounds__(64 * kGramWaves) void k_gramstep(
                 const V rf = s_r[wave][4 * (u0 + u) + g];
 #pragma unroll
                 for (int e = 0; e < NV; ++e) {
-                    const double a0 = (double)xf[u][0][e];
+                    double a[NG];
+#pragma unroll
+                    for (int grp = 0; grp < NG; ++grp) a[grp] = (double)xf[u][grp][e];
                     const double rb = (double)rf[e];
-                    tile[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, tile[0], 0, 0, 0);
-                    ctile[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, rb, ctile[0], 0, 0, 0);
-                    if constexpr (NG == 2) {
-                        const double a1 = (double)xf[u][1][e];
-                        tile[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, tile[1], 0, 0, 0);
-                        tile[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, tile[2], 0, 0, 0);
-                        ctile[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, rb, ctile[1], 0, 0, 0);
+#pragma unroll
+                    for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+                        for (int gj = gi; gj < NG; ++gj)
+                            tile[R::tile(gi, gj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                a[gi], a[gj], tile[R::tile(gi, gj)], 0, 0, 0);
+                        ctile[gi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gi], rb, ctile[gi], 0, 0, 0);
                     }
                 }
             }
@@ -163,25 +169,36 @@ __global__ __launch_bounds__(64 * kGramWaves) void k_gramstep(
         __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- per-wave record -> LDS -> sum over the block's waves -> value-major partials ----------
+    // ---- per-wave record -> LDS -> sum over the block's waves -> value-major partials, one tile
+    // at a time (an 8 KB staging buffer instead of the whole record x 4 waves) --------------------
     qacc = wave_sum(qacc);
 #pragma unroll
-    for (int t = 0; t < R::NT; ++t)
+    for (int t = 0; t < R::NT; ++t) {
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) s_red[wave][t * 256 + (g + 4 * q4) * 16 + c] = tile[t][q4];
+        for (int q4 = 0; q4 < 4; ++q4) s_red[wave][(g + 4 * q4) * 16 + c] = tile[t][q4];
+        __syncthreads();
+        {
+            const int v = threadIdx.x;   // 256 threads, 256 tile elements
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < kGramWaves; ++w) sum += s_red[w][v];
+            partials[(int64_t)(t * 256 + v) * gridDim.x + blockIdx.x] = sum;
+        }
+        __syncthreads();
+    }
     if (c == 0) {
 #pragma unroll
         for (int t = 0; t < NG; ++t)
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) s_red[wave][R::OFF_C + 16 * t + g + 4 * q4] = ctile[t][q4];
+            for (int q4 = 0; q4 < 4; ++q4) s_red[wave][16 * t + g + 4 * q4] = ctile[t][q4];
     }
-    if (lane == 0) s_red[wave][R::OFF_Q] = qacc;
+    if (lane == 0) s_red[wave][B] = qacc;
     __syncthreads();
-    for (int v = threadIdx.x; v < R::N; v += blockDim.x) {
-        double s = 0.0;
+    for (int v = threadIdx.x; v < B + 1; v += blockDim.x) {
+        double sum = 0.0;
 #pragma unroll
-        for (int w = 0; w < kGramWaves; ++w) s += s_red[w][v];
-        partials[(int64_t)v * gridDim.x + blockIdx.x] = s;
+        for (int w = 0; w < kGramWaves; ++w) sum += s_red[w][v];
+        partials[(int64_t)(R::OFF_C + v) * gridDim.x + blockIdx.x] = sum;
     }
 }
 
@@ -194,6 +211,15 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
         const double s = wave_sum_run(partials + (int64_t)v * nparts, nparts, lane);
         if (lane == 0) rec[v] = s;
     }
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(v), lane));
 }
 
 // Stage 2: the B sequential scalar updates, one wave, lane i owns visit i of the block:
@@ -226,12 +252,13 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
     for (int s = 0; s < nb; ++s) {
         const VisitOut o = visit_update(loss, lambda0, n_total, a_me, b_me, q, old_me, om_me);
         const double h_cand = o.nv - old_me;
-        const double h_s = __shfl(h_cand, s, 64);
-        const double nv_s = __shfl(o.nv, s, 64);
-        const double b_s = __shfl(b_me, s, 64);
-        const double a_s = __shfl(a_me, s, 64);
-        const int64_t k_s = __shfl(k_me, s, 64);
-        dom |= __shfl(o.dom, s, 64);
+        // s is wave-uniform: v_readlane broadcasts (no LDS round trip as __shfl would take)
+        const double h_s = readlane_f64(h_cand, s);
+        const double nv_s = readlane_f64(o.nv, s);
+        const double b_s = readlane_f64(b_me, s);
+        const double a_s = readlane_f64(a_me, s);
+        const int64_t k_s = (int64_t)readlane_u64((uint64_t)k_me, s);
+        dom |= __builtin_amdgcn_readlane(o.dom, s);
         if (lane == s) { nv_me = o.nv; h_me = h_cand; t_me = o.tch; }
         if (mine && lane > s) {
             b_me = fma(-h_s, rec[R::g(s, lane)], b_me);
@@ -245,7 +272,7 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
     if (lane == 0) { ctrl->maxH = maxH; if (dom) ctrl->domain_error = 1; }
     bool last = true;                                // last writer of a repeated coordinate wins
     for (int j = 1; j < nb; ++j) {
-        const int64_t k_j = __shfl(k_me, j, 64);
+        const int64_t k_j = (int64_t)readlane_u64((uint64_t)k_me, j);
         if (j > lane && k_j == k_me) last = false;
     }
     if (mine) {

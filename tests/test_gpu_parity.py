@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 BETA_TOL = 1e-10
-MODES = [("coord", 0), ("block", 8), ("block", 4), ("block", 2), ("block", 16), ("block", 32)]
+MODES = [("coord", 0), ("block", 8), ("block", 4), ("block", 2), ("block", 16), ("block", 32), ("block", 64)]
 
 
 def _problem(seed, n, p, s, noise=1.0):
@@ -86,7 +86,7 @@ def test_pass_trajectory_matches_golden(name, mode):
 SOLVES = sorted(os.path.basename(c)[:-4] for c in glob.glob(os.path.join(GOLD, "*.npz")) if "traj" not in c)
 
 
-@pytest.mark.parametrize("mode", [MODES[0], MODES[1], MODES[4], MODES[5]], ids=lambda m: f"{m[0]}{m[1]}")
+@pytest.mark.parametrize("mode", [MODES[0], MODES[1], MODES[4], MODES[5], MODES[6]], ids=lambda m: f"{m[0]}{m[1]}")
 @pytest.mark.parametrize("name", SOLVES)
 def test_solve_matches_golden(name, mode):
     d = np.load(os.path.join(GOLD, name + ".npz"))
@@ -259,7 +259,7 @@ def test_weighted_ls_loss_matches_oracle():
 
 
 # ---- fp32 storage (fp64 accumulation): loose, declared tolerance ------------------------------
-@pytest.mark.parametrize("mode", [MODES[0], MODES[1], MODES[4], MODES[5]], ids=lambda m: f"{m[0]}{m[1]}")
+@pytest.mark.parametrize("mode", [MODES[0], MODES[1], MODES[4], MODES[5], MODES[6]], ids=lambda m: f"{m[0]}{m[1]}")
 def test_fp32_against_fp64_oracle(mode):
     rng, X, Y = _problem(13, 4000, 64, 8)
     f = cd.CDLeastSquaresLoss(Y.astype(np.float32), X.astype(np.float32))
@@ -274,7 +274,7 @@ def test_fp32_against_fp64_oracle(mode):
 
 
 # ---- device generator + medium-size parity on device-generated data ------------------------------
-@pytest.mark.parametrize("mode", [MODES[0], MODES[1], MODES[4], MODES[5]], ids=lambda m: f"{m[0]}{m[1]}")
+@pytest.mark.parametrize("mode", [MODES[0], MODES[1], MODES[4], MODES[5], MODES[6]], ids=lambda m: f"{m[0]}{m[1]}")
 def test_generated_problem_parity_n200k(mode):
     n, p, s = 200_003, 48, 6   # odd n: ragged vector tail
     f, bstar = cd.CDLeastSquaresLoss.generate(n, p, seed=123, s=s, noise=1.0)
