@@ -95,9 +95,12 @@ struct cdh_handle_s {
     cdh::SupportList x;
     int mode = CDH_SWEEP_COORD, blockB = 8;
     bool use_graph = false;
+    bool chunk_dup = false;       // the current chunk's visit list repeats a coordinate
+    std::vector<int32_t> stamp;   // duplicate detection scratch, size p
     std::vector<std::pair<uint64_t, hipGraphExec_t>> graphs;  // captured chunk launch sequences
     bool domain_error = false;
     int step_grid = 1, block_grid = 1, gram_grid = 1, cus = 1, gram32_per_cu = 1;
+    int64_t gram_units = 1;
     bool nt = true;  // non-temporal loads for the X column streams
     // comm
     void* comm = nullptr;
@@ -136,6 +139,14 @@ int32_t fail(cdh_handle h, int32_t code, const char* msg) {
 }
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// Grid size for a grid-stride kernel with `units` work items and at most `gmax` resident blocks.
+inline int balanced_grid(int64_t units, int64_t gmax) {
+    // Measured: keeping every CU slot occupied (gmax blocks) beats equalising per-block work --
+    // the streaming rate is set per CU (~24 GB/s each), so an idle slot costs more than a block
+    // that runs one iteration longer.
+    return (int)std::max<int64_t>(1, std::min<int64_t>(gmax, units));
+}
 
 template <typename F> int32_t dispatch(cdh_handle h, F&& f) {
     return h->dtype == CDH_F64 ? f((double*)nullptr) : f((float*)nullptr);
@@ -258,7 +269,7 @@ template <typename T, int NG> void launch_gram_chunk(cdh_handle h, int m) {
     using R = GramRec<NG>;
     constexpr int B = R::B;
     // blocks per CU follow the kernel's register footprint (2 waves per SIMD for both widths)
-    const int G = std::max(1, NG >= 2 ? std::min(h->gram_grid, h->cus * h->gram32_per_cu) : h->gram_grid);
+    const int G = NG >= 2 ? balanced_grid(h->gram_units, (int64_t)h->cus * h->gram32_per_cu) : h->gram_grid;
     int nprev = 0;
     for (int pos0 = 0; pos0 < m; pos0 += B) {
         const int nb = std::min(B, m - pos0);
@@ -272,7 +283,7 @@ template <typename T, int NG> void launch_gram_chunk(cdh_handle h, int m) {
                                h->d_partials);
         hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + 3) / 4), dim3(256), 0, h->stream, h->d_partials, G, R::N, h->d_red);  // one value per wave
         allreduce(h, h->d_red, R::N);
-        hipLaunchKernelGGL((k_gram_scalar<NG>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb, h->d_ctrl,
+        hipLaunchKernelGGL((k_gram_scalar<NG>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb, h->chunk_dup ? 1 : 0, h->d_ctrl,
                            h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos0);
         nprev = nb;
     }
@@ -312,6 +323,15 @@ template <typename T> void launch_coord_chunk(cdh_handle h, int m) {
 
 int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     std::memcpy(h->h_idx, idx0, sizeof(int64_t) * (size_t)m);
+    {   // does any coordinate repeat?  (scheduler-made lists never do; caller-made ones may)
+        if ((int64_t)h->stamp.size() != h->p) h->stamp.assign((size_t)h->p, 0);
+        h->chunk_dup = false;
+        for (int i = 0; i < m; ++i) {
+            if (h->stamp[(size_t)idx0[i]]) { h->chunk_dup = true; break; }
+            h->stamp[(size_t)idx0[i]] = 1;
+        }
+        for (int i = 0; i < m; ++i) h->stamp[(size_t)idx0[i]] = 0;
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
     h->ctrl.maxH = 0.0;
     h->ctrl.domain_error = 0;
@@ -337,7 +357,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     // communicator: RCCL calls are left out of stream capture.)
     if (h->use_graph && !h->comm) {
         const uint64_t key = ((uint64_t)m << 16) | ((uint64_t)(blocked ? h->blockB : 0) << 4) |
-                             (h->has_w ? 2u : 0u) | (h->nt ? 1u : 0u);
+                             (h->chunk_dup ? 4u : 0u) | (h->has_w ? 2u : 0u) | (h->nt ? 1u : 0u);
         hipGraphExec_t exec = nullptr;
         for (auto& e : h->graphs) if (e.first == key) exec = e.second;
         if (!exec) {
@@ -527,13 +547,14 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         const int step_per_cu = std::max(1, env_int("CDH_STEP_GRID_PER_CU", 8));
         const int block_per_cu = std::max(1, std::min(kBlockGridPerCU, env_int("CDH_BLOCK_GRID_PER_CU", 3)));
         const int64_t want = (h->nvec + (int64_t)kBlock * kUnroll - 1) / ((int64_t)kBlock * kUnroll);
-        h->step_grid = (int)std::max<int64_t>(1, std::min<int64_t>({want, (int64_t)kMaxStepGrid, (int64_t)cus * step_per_cu}));
+        h->step_grid = balanced_grid(want, std::min<int64_t>((int64_t)kMaxStepGrid, (int64_t)cus * step_per_cu));
         const int64_t wantb = (h->nvec + kBlock - 1) / kBlock;
-        h->block_grid = (int)std::max<int64_t>(1, std::min<int64_t>(wantb, (int64_t)cus * block_per_cu));
+        h->block_grid = balanced_grid(wantb, (int64_t)cus * block_per_cu);
         h->cus = cus;
-        h->gram32_per_cu = std::max(1, env_int("CDH_GRAM32_GRID_PER_CU", 2));
+        h->gram32_per_cu = std::max(1, env_int("CDH_GRAM32_GRID_PER_CU", 3));
         const int64_t wantg = (h->nvec + 64 * kGramWaves - 1) / (64 * kGramWaves);
-        h->gram_grid = (int)std::max<int64_t>(1, std::min<int64_t>(wantg, (int64_t)cus * std::max(1, env_int("CDH_GRAM_GRID_PER_CU", 2))));
+        h->gram_grid = balanced_grid(wantg, (int64_t)cus * std::max(1, env_int("CDH_GRAM_GRID_PER_CU", 2)));
+        h->gram_units = wantg;
         const size_t colbytes = (size_t)h->ld * h->esz;
         HIPCHK(h, hipMalloc(&h->X, colbytes * (size_t)p));
         HIPCHK(h, hipMalloc(&h->y, colbytes));

@@ -65,13 +65,18 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
     // previous block's updates, compacted to those with h != 0 (no per-column branches in the
     // streaming loop: conditional loads would be waited for one by one)
     __shared__ int s_nzp;
-    if (threadIdx.x == 0) {
-        int m = 0;
-        for (int i = 0; i < nprev; ++i) {
-            const double h = hs[pos0 - nprev + i];
-            if (h != 0.0) { s_hp[m] = h; s_kp[m] = idx[pos0 - nprev + i]; ++m; }
+    if (threadIdx.x < 64) {   // wave 0: all entries fetched at once, compacted with a ballot
+        const int i = threadIdx.x;
+        double h = 0.0;
+        int64_t kp = 0;
+        if (i < nprev) { h = hs[pos0 - nprev + i]; kp = idx[pos0 - nprev + i]; }
+        const bool nz = (h != 0.0);
+        const unsigned long long mask = __ballot(nz);
+        if (nz) {
+            const int at = __popcll(mask & ((1ull << i) - 1ull));
+            s_hp[at] = h; s_kp[at] = kp;
         }
-        s_nzp = m;
+        if (i == 0) s_nzp = __popcll(mask);
     }
     __syncthreads();
     const int nzp = s_nzp;
@@ -225,60 +230,91 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // Stage 2: the B sequential scalar updates, one wave, lane i owns visit i of the block:
 //   b_i = c_i - sum_{s<i} h_s G_si is kept current by a lane-parallel rank-1 update after each
 //   visit; q_s = q_{s-1} - 2 h_{s-1} b_{s-1} + h_{s-1}^2 a_{s-1}  (kernels.hpp, same identities).
+// The loop is fully unrolled and carries only the dependent chain
+//   v = b_s / a_s + beta_s -> S(v, thr_s) -> h_s -> broadcast -> b_j -= h_s G_sj ;
+// G's column, 1/a and the threshold are fetched / computed by all lanes before it, and maxH,
+// the touched flags and the stores come after it.  `dup` says a coordinate may repeat inside
+// the block (only caller-supplied visit lists can do that): later visits then see the new value.
 template <int NG>
-__global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ rec_g, int nb, Ctrl* ctrl,
-                                                    double* beta, const double* __restrict__ omega,
+__global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ rec_g, int nb, int dup,
+                                                    Ctrl* ctrl, double* beta,
+                                                    const double* __restrict__ omega,
                                                     const int64_t* __restrict__ idx, double* hs,
                                                     double* newval, int32_t* touched, int pos0) {
     using R = GramRec<NG>;
-    __shared__ double rec[R::N];
+    constexpr int B = R::B;
     const int lane = threadIdx.x;
-    for (int v = lane; v < R::N; v += 64) rec[v] = rec_g[v];
-    __builtin_amdgcn_wave_barrier();
     const bool mine = lane < nb;
     const int li = mine ? lane : 0;
+    // independent loads first: this lane's column of G, c, a, the iterate and the weights
     const int64_t k_me = idx[pos0 + li];
-    double old_me = beta[k_me];
-    const double om_me = ctrl->has_omega ? omega[k_me] : 1.0;
-    double b_me = rec[R::OFF_C + li];
-    const double a_me = rec[R::g(li, li)];
-    double q = rec[R::OFF_Q];
+    double gcol[B];
+#pragma unroll
+    for (int s = 0; s < B; ++s) gcol[s] = rec_g[R::g(s < li ? s : li, li)];   // G[s][li], s < li
+    double b_me = rec_g[R::OFF_C + li];
+    const double a_me = rec_g[R::g(li, li)];
+    double q = rec_g[R::OFF_Q];
     const int loss = ctrl->loss;
     const double lambda0 = ctrl->lambda0, n_total = ctrl->n_total;
-    double maxH = ctrl->maxH;
+    const double maxH0 = ctrl->maxH;
+    const double om_me = ctrl->has_omega ? omega[k_me] : 1.0;
+    double old_me = beta[k_me];
+    const double ia_me = 1.0 / a_me;
+    const double thr_me = lambda0 * om_me * (n_total * ia_me);
     int dom = 0;
-    double nv_me = 0.0, h_me = 0.0;
-    int32_t t_me = 0;
-    for (int s = 0; s < nb; ++s) {
-        const VisitOut o = visit_update(loss, lambda0, n_total, a_me, b_me, q, old_me, om_me);
-        const double h_cand = o.nv - old_me;
-        // s is wave-uniform: v_readlane broadcasts (no LDS round trip as __shfl would take)
-        const double h_s = readlane_f64(h_cand, s);
-        const double nv_s = readlane_f64(o.nv, s);
-        const double b_s = readlane_f64(b_me, s);
-        const double a_s = readlane_f64(a_me, s);
-        const int64_t k_s = (int64_t)readlane_u64((uint64_t)k_me, s);
-        dom |= __builtin_amdgcn_readlane(o.dom, s);
-        if (lane == s) { nv_me = o.nv; h_me = h_cand; t_me = o.tch; }
-        if (mine && lane > s) {
-            b_me = fma(-h_s, rec[R::g(s, lane)], b_me);
-            if (k_me == k_s) old_me = nv_s;          // the same coordinate later in this block
+    double v_me = 0.0, nv_me = 0.0, h_me = 0.0;
+#pragma unroll
+    for (int s = 0; s < B; ++s) {
+        if (s < nb) {   // wave-uniform
+            double v, nv;
+            if (loss == 1 /* CDH_SQRT */) {
+                const VisitOut o = visit_update_rcp(loss, lambda0, n_total, a_me, ia_me, b_me, q, old_me, om_me);
+                v = 0.0; nv = o.nv;
+                dom |= __builtin_amdgcn_readlane(o.dom, s);
+            } else {
+                v = fma(b_me, ia_me, old_me);
+                nv = soft_threshold(v, thr_me);
+            }
+            const double hc = nv - old_me;
+            const double h_s = readlane_f64(hc, s);
+            if (lane == s) { v_me = v; nv_me = nv; h_me = hc; }
+            if (loss == 1) {
+                const double b_s = readlane_f64(b_me, s), a_s = readlane_f64(a_me, s);
+                q = q - 2.0 * h_s * b_s + h_s * h_s * a_s;
+                if (q < 0.0) q = 0.0;
+            }
+            if (dup) {
+                const int64_t k_s = (int64_t)readlane_u64((uint64_t)k_me, s);
+                const double nv_s = readlane_f64(nv, s);
+                if (lane > s && k_me == k_s) old_me = nv_s;
+            }
+            b_me = fma(-h_s, gcol[s], b_me);   // only lanes > s still use b_me
         }
-        const double ah = fabs(h_s);
-        if (ah > maxH || ah != ah) maxH = ah;
-        q = q - 2.0 * h_s * b_s + h_s * h_s * a_s;
-        if (q < 0.0) q = 0.0;
     }
-    if (lane == 0) { ctrl->maxH = maxH; if (dom) ctrl->domain_error = 1; }
+    // maxH over the block's visits (NaN sticks), then the stores
+    double ah = mine ? fabs(h_me) : 0.0;
+    const bool any_nan = __ballot(ah != ah) != 0ull;
+    double m = (ah != ah) ? 0.0 : ah;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if (lane == 0) {
+        double mh = maxH0;
+        if (m > mh) mh = m;
+        if (any_nan || mh != mh) mh = __builtin_nan("");
+        ctrl->maxH = mh;
+        if (dom) ctrl->domain_error = 1;
+    }
     bool last = true;                                // last writer of a repeated coordinate wins
-    for (int j = 1; j < nb; ++j) {
-        const int64_t k_j = (int64_t)readlane_u64((uint64_t)k_me, j);
-        if (j > lane && k_j == k_me) last = false;
+    if (dup) {
+        for (int j = 1; j < nb; ++j) {
+            const int64_t k_j = (int64_t)readlane_u64((uint64_t)k_me, j);
+            if (j > lane && k_j == k_me) last = false;
+        }
     }
     if (mine) {
         hs[pos0 + lane] = h_me;
         newval[pos0 + lane] = nv_me;
-        touched[pos0 + lane] = t_me;
+        touched[pos0 + lane] = (loss == 1) ? 0 : ((v_me != 0.0) ? 1 : 0);
         if (last) beta[k_me] = nv_me;
     }
 }
@@ -295,13 +331,18 @@ __global__ __launch_bounds__(kBlock) void k_multi_axpy(const T* __restrict__ X, 
     __shared__ double s_hp[64];
     __shared__ int64_t s_kp[64];
     __shared__ int s_nzp;
-    if (threadIdx.x == 0) {
-        int m = 0;
-        for (int i = 0; i < nprev && i < 64; ++i) {
-            const double h = hs[pos0 + i];
-            if (h != 0.0) { s_hp[m] = h; s_kp[m] = idx[pos0 + i]; ++m; }
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        double h = 0.0;
+        int64_t kp = 0;
+        if (i < nprev) { h = hs[pos0 + i]; kp = idx[pos0 + i]; }
+        const bool nz = (h != 0.0);
+        const unsigned long long mask = __ballot(nz);
+        if (nz) {
+            const int at = __popcll(mask & ((1ull << i) - 1ull));
+            s_hp[at] = h; s_kp[at] = kp;
         }
-        s_nzp = m;
+        if (i == 0) s_nzp = __popcll(mask);
     }
     __syncthreads();
     const int nzp = s_nzp;

@@ -271,6 +271,35 @@ __device__ __forceinline__ VisitOut visit_update(int loss, double lambda0, doubl
     }
     return o;
 }
+// Same update with 1/a supplied by the caller: the wide-block recurrence visits B coordinates
+// serially in one wave, and a_i does not change, so the division leaves the serial chain.
+__device__ __forceinline__ VisitOut visit_update_rcp(int loss, double lambda0, double n_total, double a,
+                                                     double ia, double b, double q, double oldv,
+                                                     double om) {
+    VisitOut o{0.0, 0, 0};
+    if (loss == 1 /* CDH_SQRT */) {
+        const double lam = lambda0 * om;
+        const double s = fma(oldv, a, b);
+        double rsqr = q + 2.0 * oldv * b + oldv * oldv * a;
+        if (rsqr < 0.0) rsqr = 0.0;
+        if (fabs(s) <= lam * sqrt(rsqr)) {
+            o.nv = 0.0;
+        } else {
+            double u = 1.0 - lam * lam * ia;
+            double v = rsqr - s * s * ia;
+            if (u <= 0.0 || v < -1e-12 * rsqr) o.dom = 1;
+            if (v < 0.0) v = 0.0;
+            if (u <= 0.0) u = 1e-300;
+            const double c = lam / sqrt(u) * sqrt(v);
+            o.nv = (s > 0.0 ? (s - c) : (s + c)) * ia;
+        }
+    } else {
+        const double v = fma(b, ia, oldv);
+        o.tch = (v != 0.0) ? 1 : 0;
+        o.nv = soft_threshold(v, lambda0 * om * (n_total * ia));
+    }
+    return o;
+}
 __device__ inline void scalar_update(double a, double b, double q, Ctrl* ctrl, double* beta,
                                      const double* omega, int64_t k, int pos, double* hs,
                                      double* newval, int32_t* touched) {
