@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libcdhip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "cdhip.h")
-SOURCES = ["cdhip.hip", "kernels.hpp", "sparse_iterate.hpp"]
+SOURCES = ["cdhip.hip", "kernels.hpp", "gram_kernels.hpp", "sparse_iterate.hpp"]
 
 CDH_OK, CDH_DIM_MISMATCH, CDH_BAD_ARG, CDH_DOMAIN, CDH_HIP_ERROR, CDH_RCCL_ERROR, CDH_OOM = range(7)
 CDH_F64, CDH_F32 = 0, 1
