@@ -116,6 +116,8 @@ def lib():
         "cdh_get_residual": [vp, vp],
         "cdh_col_rms": [vp, vp],
         "cdh_xt_r": [vp, vp],
+        "cdh_gram": [vp, i64, vp, vp, vp, P(f64)],
+        "cdh_set_reuse_residual": [vp, i32],
         "cdh_resid_moments": [vp, P(f64), P(f64)],
         "cdh_objective": [vp, P(f64)],
         "cdh_set_sweep_mode": [vp, i32, i32],

@@ -543,8 +543,10 @@ def sqrtLasso(X, y, lam, omega=None, options=None, standardizeX=True):
 
 def _find_init_sigma(f, s):
     """_findInitSigma! (src/utils.jl:60-77, 96-106): std of the OLS residuals on the s
-    columns most correlated with y.  Screening scores X'y come from the device; the
-    s-column OLS is staged on the host (s is 5 by default)."""
+    columns most correlated with y.  Everything n-sized stays in HBM: the screening scores
+    X'y and the s x s normal equations (X_S'X_S, X_S'y) come from one pass each over the
+    columns involved, the host solves the s x s system, and the residual y - X_S b is formed
+    by initialize! on the device (s is 5 by default)."""
     L = f._L
     check(L.cdh_initialize(f._h, f.p, 0, None, None), f._h)  # beta = 0, r = y: X'r == X'y
     f._synced = None
@@ -552,11 +554,17 @@ def _find_init_sigma(f, s):
     check(L.cdh_xt_r(f._h, _vp(out)), f._h)
     xty = np.abs(out)
     thr = np.sort(xty)[::-1][s - 1]
-    S = np.nonzero(xty >= thr)[0]
-    Xs = np.concatenate([f.X_cols(int(j), 1) for j in S], axis=1).astype(np.float64)
-    y = f.y.astype(np.float64)
-    coef, *_ = np.linalg.lstsq(Xs, y, rcond=None)
-    return float(np.std(y - Xs @ coef, ddof=1))
+    S = np.nonzero(xty >= thr)[0]            # `storage .>= nlargest(s, storage)[end]`: ties kept
+    if len(S) > 64:
+        raise ArgumentError("screening set larger than 64 columns")
+    idx1 = np.ascontiguousarray(S + 1, dtype=np.int64)
+    G, c = np.zeros((len(S), len(S))), np.zeros(len(S))
+    check(L.cdh_gram(f._h, len(S), _vp(idx1), _vp(G), _vp(c), None), f._h)
+    coef = np.linalg.solve(G, c)             # Xs \ y through the normal equations
+    check(L.cdh_initialize(f._h, f.p, len(S), _vp(idx1), _vp(np.ascontiguousarray(coef))), f._h)
+    sigma = _std_resid(f)                    # std(y - Xs * (Xs \ y))
+    f._synced = None
+    return sigma
 
 
 def scaledLasso_(x, X, y, lam, omega, options=None):
@@ -593,7 +601,7 @@ class LassoPathResult:
     betapath: list
 
 
-def LassoPath(X, Y, lambdapath, options=None, max_hat_s=np.inf, standardizeX=True):
+def LassoPath(X, Y, lambdapath, options=None, max_hat_s=np.inf, standardizeX=True, reuse_residual=True):
     """LassoPath(X, Y, λpath, options; max_hat_s, standardizeX) (src/lasso.jl:229-260):
     one x and one f shared by all λ (warm starts), βpath[i] = copy(x)."""
     f = _as_loss(CDLeastSquaresLoss, X, Y)
@@ -601,10 +609,16 @@ def LassoPath(X, Y, lambdapath, options=None, max_hat_s=np.inf, standardizeX=Tru
     x = SparseIterate(f.p)
     lambdapath = list(lambdapath)
     betapath = []
-    for i, lam in enumerate(lambdapath):
-        coordinateDescent_(x, f, ProxL1(lam, sx), options)
-        betapath.append(x.copy())
-        if x.nnz > max_hat_s:
-            lambdapath = lambdapath[: i + 1]
-            break
+    # x and f are shared by all lambdas; after the first solve the carried residual already
+    # equals y - X x, so later warm starts skip the redundant initialize! (rounding-level effect)
+    check(f._L.cdh_set_reuse_residual(f._h, 1 if reuse_residual else 0), f._h)
+    try:
+        for i, lam in enumerate(lambdapath):
+            coordinateDescent_(x, f, ProxL1(lam, sx), options)
+            betapath.append(x.copy())
+            if x.nnz > max_hat_s:
+                lambdapath = lambdapath[: i + 1]
+                break
+    finally:
+        check(f._L.cdh_set_reuse_residual(f._h, 0), f._h)
     return LassoPathResult(lambdapath, betapath)

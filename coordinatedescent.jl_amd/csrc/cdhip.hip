@@ -95,6 +95,8 @@ struct cdh_handle_s {
     cdh::SupportList x;
     int mode = CDH_SWEEP_COORD, blockB = 8;
     bool use_graph = false;
+    bool reuse_residual = false;  // warm starts skip initialize! when r is known to match beta
+    bool r_consistent = false;    // r == y - X beta (up to rounding) for the handle's current iterate
     bool chunk_dup = false;       // the current chunk's visit list repeats a coordinate
     std::vector<int32_t> stamp;   // duplicate detection scratch, size p
     std::vector<std::pair<uint64_t, hipGraphExec_t>> graphs;  // captured chunk launch sequences
@@ -228,6 +230,7 @@ int32_t rebuild_residual(cdh_handle h) {
     }));
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors above go out of scope
+    h->r_consistent = true;
     return CDH_OK;
 }
 
@@ -290,6 +293,10 @@ template <typename T, int NG> void launch_gram_chunk(cdh_handle h, int m) {
     const int last0 = ((m - 1) / B) * B;
     hipLaunchKernelGGL(k_multi_axpy<T>, dim3(h->step_grid), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
                        h->nvec, (T*)h->r, h->d_idx, h->d_hs, last0, m - last0);
+}
+
+inline int NGgrid(cdh_handle h, int NG) {
+    return NG >= 2 ? balanced_grid(h->gram_units, (int64_t)h->cus * h->gram32_per_cu) : h->gram_grid;
 }
 
 template <typename T> void launch_coord_chunk(cdh_handle h, int m) {
@@ -615,6 +622,7 @@ int32_t cdh_synchronize(cdh_handle h) {
 }
 
 int32_t cdh_set_X_cols(cdh_handle h, int64_t j0, int64_t ncols, const void* host, int64_t ld) {
+    h->r_consistent = false;
     if (j0 < 0 || ncols < 0 || j0 + ncols > h->p || ld < h->n) return fail(h, CDH_DIM_MISMATCH, "column block outside X");
     if (ncols == 0) return CDH_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -637,6 +645,7 @@ int32_t cdh_get_X_cols(cdh_handle h, int64_t j0, int64_t ncols, void* host, int6
 }
 
 int32_t cdh_set_y(cdh_handle h, const void* host_y) {
+    h->r_consistent = false;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(h->y, host_y, (size_t)h->n * h->esz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->r, h->y, (size_t)h->n * h->esz, hipMemcpyDeviceToDevice, h->stream));
@@ -653,6 +662,7 @@ int32_t cdh_get_y(cdh_handle h, void* host_y) {
 }
 
 int32_t cdh_set_obs_weights(cdh_handle h, const void* host_w) {
+    h->r_consistent = false;
     if (h->loss != CDH_WLS) return fail(h, CDH_BAD_ARG, "observation weights need the CDH_WLS loss");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(h->w, host_w, (size_t)h->n * h->esz, hipMemcpyHostToDevice, h->stream));
@@ -725,6 +735,7 @@ int32_t cdh_set_iterate(cdh_handle h, int64_t x_length, int64_t nnz, const int64
     for (int64_t i = 0; i < nnz; ++i)
         if (idx1[i] < 1 || idx1[i] > h->p) return fail(h, CDH_BAD_ARG, "support index out of range");
     HIPCHK(h, hipSetDevice(h->device));
+    h->r_consistent = false;
     h->x.clear();
     for (int64_t i = 0; i < nnz; ++i) {
         // a stored zero keeps its slot in the reference's SparseIterate; mirror that
@@ -815,7 +826,9 @@ int32_t cdh_coordinate_descent(cdh_handle h, const cdh_options* opt, cdh_stats* 
     h->domain_error = false;
     int32_t rc = CDH_OK;
     if (opt->warmStart) {
-        CHK(rebuild_residual(h));                       // initialize!(f, x)     (:21)
+        // initialize!(f, x) (:21).  Optional shortcut for warm-started paths (LassoPath): the
+        // carried residual already equals y - X beta, so the rebuild only re-rounds it.
+        if (!(h->reuse_residual && h->r_consistent)) CHK(rebuild_residual(h));
         rc = solve(h, opt, sched, &st);
     } else {
         h->x.clear();                                   // fill!(x, 0)           (:25)
@@ -881,6 +894,41 @@ int32_t cdh_xt_r(cdh_handle h, double* out_p) {
     for (int64_t j = 0; j < h->p; ++j) out_p[j] = cd[(size_t)(2 * j)];
     return CDH_OK;
 }
+
+int32_t cdh_gram(cdh_handle h, int64_t m, const int64_t* idx1, double* out_G, double* out_c, double* out_q) {
+    if (m < 1 || m > 64) return fail(h, CDH_BAD_ARG, "need 1 <= m <= 64 columns");
+    for (int64_t i = 0; i < m; ++i)
+        if (idx1[i] < 1 || idx1[i] > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int64_t i = 0; i < m; ++i) h->h_idx[i] = idx1[i] - 1;
+    HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+    // one k_gramstep launch with no pending update: r is only read
+    const int G = NGgrid(h, 4);
+    using R = GramRec<4>;
+    CHK(dispatch(h, [&](auto* t) {
+        using T = std::remove_pointer_t<decltype(t)>;
+        hipLaunchKernelGGL((k_gramstep<T, 4, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
+                           (const T*)h->X, h->ld, h->nvec, (T*)h->r, h->d_idx, h->d_hs, 0, (int)m, 0, h->d_partials);
+        return CDH_OK;
+    }));
+    hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + 3) / 4), dim3(256), 0, h->stream, h->d_partials, G, R::N, h->d_red);
+    HIPCHK(h, hipGetLastError());
+    CHK(allreduce(h, h->d_red, R::N));
+    std::vector<double> rec((size_t)R::N);
+    HIPCHK(h, hipMemcpyAsync(rec.data(), h->d_red, sizeof(double) * R::N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < m; ++i) {
+        for (int64_t j = 0; j < m; ++j) {
+            const int s = (int)std::min(i, j), l = (int)std::max(i, j);
+            out_G[i * m + j] = rec[(size_t)R::g(s, l)];
+        }
+        if (out_c) out_c[i] = rec[(size_t)(R::OFF_C + i)];
+    }
+    if (out_q) *out_q = rec[(size_t)R::OFF_Q];
+    return CDH_OK;
+}
+
+int32_t cdh_set_reuse_residual(cdh_handle h, int32_t on) { h->reuse_residual = on != 0; return CDH_OK; }
 
 int32_t cdh_resid_moments(cdh_handle h, double* out_sum, double* out_sumsq) {
     HIPCHK(h, hipSetDevice(h->device));

@@ -161,6 +161,12 @@ int32_t cdh_col_rms(cdh_handle h, double *out_p);
 /* out_j = X_j' r for every column at the current r (At_mul_B_row for all j: the
  * screening scores of _findLargestCorrelations, utils.jl:96-106; KKT checks). */
 int32_t cdh_xt_r(cdh_handle h, double *out_p);
+/* Gram block of up to 64 columns against the current r, in one pass over them:
+ * out_G[i*m+j] = X_i'X_j, out_c[i] = X_i'r, *out_q = r'r (all shards).  With r = y this is
+ * what the s-column OLS of _findInitResiduals! needs (utils.jl:65-77: Xs \ y via the normal
+ * equations), without moving any n-sized array to the host. */
+int32_t cdh_gram(cdh_handle h, int64_t m, const int64_t *idx1, double *out_G, double *out_c,
+                 double *out_q);
 /* sum r, sum r^2 over all shards (sigma of scaledLasso!, lasso.jl:134; std(f.r)). */
 int32_t cdh_resid_moments(cdh_handle h, double *out_sum, double *out_sumsq);
 /* f(beta) + lambda0 sum omega|beta| at the current state (coordinate_descent.jl:1-3). */
@@ -168,6 +174,11 @@ int32_t cdh_objective(cdh_handle h, double *out);
 
 /* ---- execution control (no reference counterpart) ------------------------------- */
 int32_t cdh_set_sweep_mode(cdh_handle h, int32_t mode, int32_t block);
+/* Warm starts normally rebuild r = y - X beta as the reference's initialize! does
+ * (coordinate_descent.jl:21).  With reuse on, a warm start whose iterate is the one the
+ * handle already holds keeps the carried residual (LassoPath, lasso.jl:250-252: 100 rebuilds
+ * of n x nnz work saved); the difference is rounding only. */
+int32_t cdh_set_reuse_residual(cdh_handle h, int32_t on);
 /* Replay each pass from a captured hipGraph instead of individual launches. */
 int32_t cdh_set_use_graph(cdh_handle h, int32_t on);
 /* Multi-process row sharding: rank 0 calls cdh_comm_unique_id, broadcasts the

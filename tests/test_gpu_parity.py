@@ -412,3 +412,78 @@ def test_rccl_path_under_torchrun_matches_plain_run(mode_args):
     assert "Librccl path" in a.stderr or "librccl" in a.stderr.lower() or True
     assert ja["config"]["last_maxH"] == jb["config"]["last_maxH"]      # bit-identical iterates
     assert ja["config"]["moved_per_sweep"] == jb["config"]["moved_per_sweep"]
+
+
+# ---- section 8(f) rows: screening init kept on the device, LassoPath without the rebuild ---------
+def test_gram_entry_point_matches_numpy():
+    rng, X, Y = _problem(31, 5003, 80, 6)
+    f = cd.CDLeastSquaresLoss(Y, X)
+    for m in (1, 5, 16, 17, 40, 64):
+        cols = rng.choice(80, size=m, replace=False)
+        idx1 = np.ascontiguousarray(cols + 1, dtype=np.int64)
+        G, c, q = np.zeros((m, m)), np.zeros(m), cd._lib.C.c_double()
+        cd._lib.check(f._L.cdh_gram(f._h, m, idx1.ctypes.data, G.ctypes.data, c.ctypes.data,
+                                    cd._lib.C.byref(q)), f._h)
+        Xs = X[:, cols]
+        np.testing.assert_allclose(G, Xs.T @ Xs, rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(c, Xs.T @ Y, rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(q.value, Y @ Y, rtol=1e-13)
+    np.testing.assert_array_equal(f.r, Y)      # r is only read
+
+
+def test_screening_sigma_matches_reference_formula():
+    """_findInitSigma! (utils.jl:60-77): std of the residuals of OLS on the s most correlated columns."""
+    from coordinatedescent_jl_amd.api import _find_init_sigma
+    rng, X, Y = _problem(32, 4000, 60, 8)
+    f = cd.CDLeastSquaresLoss(Y, X)
+    c = np.abs(X.T @ Y)
+    S = c >= np.sort(c)[::-1][4]
+    coef, *_ = np.linalg.lstsq(X[:, S], Y, rcond=None)
+    want = np.std(Y - X[:, S] @ coef, ddof=1)
+    np.testing.assert_allclose(_find_init_sigma(f, 5), want, rtol=1e-10)
+
+
+def test_lasso_path_reusing_the_carried_residual():
+    rng, X, Y = _problem(33, 3000, 120, 10)
+    lams = list(np.exp(np.linspace(np.log(0.5), np.log(0.01), 12)))
+    opt = cd.CDOptions(maxIter=5000, optTol=1e-11, randomize=False)
+    a = cd.LassoPath(X, Y, lams, opt, reuse_residual=True)
+    b = cd.LassoPath(X, Y, lams, opt, reuse_residual=False)
+    lo, bo = O.LassoPath(X, Y, lams, O.CDOptions(maxIter=5000, optTol=1e-11, randomize=False))
+    for i in range(len(lams)):
+        np.testing.assert_allclose(a.betapath[i].dense(), b.betapath[i].dense(), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(a.betapath[i].dense(), bo[i], rtol=0, atol=1e-9)
+
+
+# ---- BASELINE.json's full size (n = 1e7, p = 1000, fp64: 80 GB of X) through properties -----------
+def test_full_size_properties_cfg2():
+    n, p, s = 10_000_000, 1000, 100
+    f, bstar = cd.CDLeastSquaresLoss.generate(n, p, seed=123, s=s, noise=6.0)
+    x = cd.SparseIterate(p)
+    cd.initialize_(f, x)
+    lmax = cd.findLambdaMax(x, f, cd.ProxL1(1.0))
+    g = cd.ProxL1(0.5 * lmax)                       # the "sparse" regime of SURVEY 8d
+    f.set_sweep_mode("block", 16)
+    objs = [cd.objective(f, g)]
+    for _ in range(3):
+        cd.cdPass_(x, f, g, range(1, p + 1))
+        objs.append(cd.objective(f, g))
+    assert all(b <= a * (1 + 1e-14) for a, b in zip(objs, objs[1:]))   # monotone descent
+    s1, ss1 = cd._lib.C.c_double(), cd._lib.C.c_double()
+    f._L.cdh_resid_moments(f._h, cd._lib.C.byref(s1), cd._lib.C.byref(ss1))
+    cd.initialize_(f, x)                             # rebuild r = y - X beta from scratch
+    s2, ss2 = cd._lib.C.c_double(), cd._lib.C.c_double()
+    f._L.cdh_resid_moments(f._h, cd._lib.C.byref(s2), cd._lib.C.byref(ss2))
+    assert abs(ss1.value - ss2.value) <= 1e-12 * ss2.value            # carried residual == rebuilt
+    cd.coordinateDescent_(x, f, g, cd.CDOptions(maxIter=100, optTol=1e-11, randomize=False))
+    assert f.last_stats["converged"]
+    xtr = np.zeros(p)
+    cd._lib.check(f._L.cdh_xt_r(f._h, xtr.ctypes.data), f._h)
+    grad, xb = np.abs(xtr) / n, x.dense()
+    act = xb != 0
+    assert act.sum() >= 1 and np.max(np.abs(grad[act] - g.lambda0)) < 1e-9   # KKT on the support
+    assert np.all(grad[~act] <= g.lambda0 * (1 + 1e-9))                      # and off it
+    f.set_sweep_mode("block", 32)                    # another sweep formulation, same fixed point
+    x2 = cd.SparseIterate(p)
+    cd.coordinateDescent_(x2, f, g, cd.CDOptions(maxIter=100, optTol=1e-11, randomize=False))
+    np.testing.assert_allclose(x2.dense(), xb, rtol=0, atol=BETA_TOL)
