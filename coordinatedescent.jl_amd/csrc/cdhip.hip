@@ -176,14 +176,18 @@ int32_t col_dots(cdh_handle h, int64_t j0, int64_t nc, const void* rvec, bool us
     // batches of at most 4096 columns keep the partial buffer small
     for (int64_t b0 = 0; b0 < nc; b0 += 4096) {
         const int64_t bc = std::min<int64_t>(4096, nc - b0);
-        const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(kColChunks, (h->nvec + kBlock - 1) / kBlock));
-        if ((size_t)bc * chunks * 2 > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partials too small");
-        dim3 grid(chunks, (unsigned)bc);
+        const int64_t groups = (bc + kColGroup - 1) / kColGroup;
+        // enough row chunks to fill the chip (~8 blocks per CU) but no more than kColChunks
+        const int64_t want_chunks = std::max<int64_t>(1, ((int64_t)h->cus * 8 + groups - 1) / groups);
+        const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)kColChunks, want_chunks,
+                                                                          (h->nvec + kBlock - 1) / kBlock}));
+        if ((size_t)groups * chunks * 2 * kColGroup > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partials too small");
+        dim3 grid(chunks, (unsigned)groups);
         CHK(dispatch(h, [&](auto* t) {
             using T = std::remove_pointer_t<decltype(t)>;
             hipLaunchKernelGGL(k_col_dots<T>, grid, dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
                                h->nvec, use_w ? (const T*)h->w : (const T*)nullptr, (const T*)rvec,
-                               j0 + b0, h->d_partials);
+                               j0 + b0, (int)bc, h->d_partials);
             return CDH_OK;
         }));
         hipLaunchKernelGGL(k_col_dots_reduce, dim3((unsigned)bc), dim3(64), 0, h->stream,

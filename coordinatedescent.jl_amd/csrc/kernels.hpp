@@ -647,58 +647,70 @@ __global__ __launch_bounds__(kBlock) void k_init_resid(const T* __restrict__ X, 
 }
 
 // ---------------------------------------------------------------------------------
-// Batched column dots (GEMV-T shape): for column j0 + blockIdx.y,
+// Batched column dots (GEMV-T shape): block (chunk, group) handles kColGroup consecutive
+// columns j0 + group*kColGroup + i over one row chunk, reading r (and w) ONCE for the group:
 //   out0 = sum w x r,  out1 = sum w x^2      (w = 1 when w == nullptr)
-// grid.x row chunks -> partials[(col, chunk, 2)], reduced by k_col_dots_reduce.
+// partials[((group * nchunks + chunk) * kColGroup + i) * 2 + {0,1}], reduced by k_col_dots_reduce.
 // ---------------------------------------------------------------------------------
+constexpr int kColGroup = 8;
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_col_dots(const T* __restrict__ X, int64_t ld,
                                                      int64_t nvec, const T* __restrict__ w,
-                                                     const T* __restrict__ r, int64_t j0,
+                                                     const T* __restrict__ r, int64_t j0, int ncols,
                                                      double* __restrict__ partials) {
     using V = typename VecOf<T>::V;
     constexpr int NV = VecOf<T>::N;
-    __shared__ double lds[2 * (kBlock / 64)];
-    const V* cv = reinterpret_cast<const V*>(X + (j0 + blockIdx.y) * ld);
+    __shared__ double lds[2 * kColGroup * (kBlock / 64)];
+    const int c0 = blockIdx.y * kColGroup;
+    const V* cv[kColGroup];
+#pragma unroll
+    for (int i = 0; i < kColGroup; ++i)   // columns past the end alias the group's first (discarded)
+        cv[i] = reinterpret_cast<const V*>(X + (j0 + (c0 + i < ncols ? c0 + i : c0)) * ld);
     const V* rv = reinterpret_cast<const V*>(r);
     const V* wv = reinterpret_cast<const V*>(w);
-    double acc[2] = {0.0, 0.0};
+    double acc[2 * kColGroup];
+#pragma unroll
+    for (int i = 0; i < 2 * kColGroup; ++i) acc[i] = 0.0;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nvec; j += stride) {
-        const V xv = cv[j];
+        V xv[kColGroup];
+#pragma unroll
+        for (int i = 0; i < kColGroup; ++i) xv[i] = ld_stream<true>(cv[i] + j);
         const V rr = rv[j];
-        const T* xp = reinterpret_cast<const T*>(&xv);
-        const T* rp = reinterpret_cast<const T*>(&rr);
-        if (w) {
-            const V wwv = wv[j];
-            const T* wp = reinterpret_cast<const T*>(&wwv);
+        V wwv = rr;
+        if (w) wwv = wv[j];
 #pragma unroll
-            for (int e = 0; e < NV; ++e) {
-                const double wx = (double)wp[e] * (double)xp[e];
-                acc[0] = fma(wx, (double)rp[e], acc[0]);
-                acc[1] = fma(wx, (double)xp[e], acc[1]);
-            }
-        } else {
+        for (int e = 0; e < NV; ++e) {
+            const double re = (double)rr[e];
+            const double we = w ? (double)wwv[e] : 1.0;
 #pragma unroll
-            for (int e = 0; e < NV; ++e) {
-                acc[0] = fma((double)xp[e], (double)rp[e], acc[0]);
-                acc[1] = fma((double)xp[e], (double)xp[e], acc[1]);
+            for (int i = 0; i < kColGroup; ++i) {
+                const double wx = we * (double)xv[i][e];
+                acc[2 * i] = fma(wx, re, acc[2 * i]);
+                acc[2 * i + 1] = fma(wx, (double)xv[i][e], acc[2 * i + 1]);
             }
         }
     }
-    block_sum<2>(acc, lds);
+    block_sum<2 * kColGroup>(acc, lds);
     if (threadIdx.x == 0) {
-        double* out = partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
-        out[0] = acc[0]; out[1] = acc[1];
+        double* out = partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * kColGroup);
+#pragma unroll
+        for (int i = 0; i < 2 * kColGroup; ++i) out[i] = acc[i];
     }
 }
+// one wave per column: out[2*col + {0,1}] = sum over chunks
 __global__ __launch_bounds__(64) void k_col_dots_reduce(const double* __restrict__ partials,
                                                         int nchunks, double* __restrict__ out) {
-    const double* pr = partials + (int64_t)blockIdx.x * nchunks * 2;
+    const int col = blockIdx.x, grp = col / kColGroup, i = col % kColGroup;
+    const double* pr = partials + (int64_t)grp * nchunks * (2 * kColGroup) + 2 * i;
     double s0 = 0.0, s1 = 0.0;
-    for (int i = threadIdx.x; i < nchunks; i += 64) { s0 += pr[2 * i]; s1 += pr[2 * i + 1]; }
+    for (int c = threadIdx.x; c < nchunks; c += 64) {
+        s0 += pr[(int64_t)c * (2 * kColGroup)];
+        s1 += pr[(int64_t)c * (2 * kColGroup) + 1];
+    }
     s0 = wave_sum(s0); s1 = wave_sum(s1);
-    if (threadIdx.x == 0) { out[2 * blockIdx.x] = s0; out[2 * blockIdx.x + 1] = s1; }
+    if (threadIdx.x == 0) { out[2 * col] = s0; out[2 * col + 1] = s1; }
 }
 
 // sum r, sum r^2 (+ sum w r^2 when w) -> partials[(block, 4)]
