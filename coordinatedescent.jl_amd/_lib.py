@@ -13,7 +13,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libcdhip.so")
+# CDHIP_SO selects another build of the same library (kernel experiments); default is in-tree.
+SO_PATH = os.environ.get("CDHIP_SO") or os.path.join(CSRC, "libcdhip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "cdhip.h")
 SOURCES = ["cdhip.hip", "kernels.hpp", "gram_kernels.hpp", "sparse_iterate.hpp"]
 
