@@ -283,6 +283,9 @@ class _HipLoss(CoordinateDifferentiableFunction):
         mode = {"coord": CDH_SWEEP_COORD, "block": CDH_SWEEP_BLOCK}.get(mode, mode)
         check(self._L.cdh_set_sweep_mode(self._h, int(mode), int(block)), self._h)
 
+    def set_screening(self, on=True):
+        check(self._L.cdh_set_screening(self._h, int(bool(on))), self._h)
+
     def set_use_graph(self, on=True):
         check(self._L.cdh_set_use_graph(self._h, int(bool(on))), self._h)
 

@@ -95,6 +95,7 @@ struct cdh_handle_s {
     cdh::SupportList x;
     int mode = CDH_SWEEP_COORD, blockB = 8;
     bool use_graph = false;
+    bool screening = true;        // solves screen their full passes over sparse iterates
     bool reuse_residual = false;  // warm starts skip initialize! when r is known to match beta
     bool r_consistent = false;    // r == y - X beta (up to rounding) for the handle's current iterate
     bool chunk_dup = false;       // the current chunk's visit list repeats a coordinate
@@ -172,7 +173,8 @@ int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
 }
 
 // ---- column dots over columns [j0, j0+nc): d_colout[2*j + {0,1}] = (x.r (w), x.x (w)) ----
-int32_t col_dots(cdh_handle h, int64_t j0, int64_t nc, const void* rvec, bool use_w) {
+int32_t col_dots(cdh_handle h, int64_t j0, int64_t nc, const void* rvec, bool use_w,
+                 const int64_t* d_cols = nullptr) {
     // batches of at most 4096 columns keep the partial buffer small
     for (int64_t b0 = 0; b0 < nc; b0 += 4096) {
         const int64_t bc = std::min<int64_t>(4096, nc - b0);
@@ -187,7 +189,7 @@ int32_t col_dots(cdh_handle h, int64_t j0, int64_t nc, const void* rvec, bool us
             using T = std::remove_pointer_t<decltype(t)>;
             hipLaunchKernelGGL(k_col_dots<T>, grid, dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
                                h->nvec, use_w ? (const T*)h->w : (const T*)nullptr, (const T*)rvec,
-                               j0 + b0, (int)bc, h->d_partials);
+                               j0 + b0, (int)bc, d_cols, h->d_partials);
             return CDH_OK;
         }));
         hipLaunchKernelGGL(k_col_dots_reduce, dim3((unsigned)bc), dim3(64), 0, h->stream,
@@ -434,11 +436,86 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
 }
 
 // _cdPass! (coordinate_descent.jl:94-110)
-int32_t run_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH) {
+// Screening of a FULL pass (exact, no reference counterpart).  A visit of a coordinate with
+// beta_k == 0 leaves everything unchanged unless |X_k'r| exceeds its threshold (LS: lambda n w_k,
+// cd_differentiable_function.jl:101-104 with x[k] == 0; SQRT: lambda w_k ||r||, :276), and as long
+// as nothing moves r does not change -- so one pass over S columns that only takes their dots
+// settles a whole run of such visits, and the Gram machinery is started at the first visit that
+// can move.  Same iterates as visiting one by one; a full pass over a sparse iterate then reads X
+// about once, at the plain streaming rate.  A 1e-9 relative margin sends borderline coordinates
+// through the exact path.  After a hit the next `cool` visits are not screened (doubling on
+// repeated hits), so a pass in which everything moves pays for a handful of screens only.
+constexpr int kScreen = 64;
+
+int32_t screened_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH) {
+    const int B = (h->mode == CDH_SWEEP_BLOCK) ? h->blockB : 1;
+    const double lam = h->ctrl.lambda0, nt = (double)h->n_total;
+    std::vector<double> om;
+    if (h->has_omega) {
+        om.resize((size_t)h->p);
+        HIPCHK(h, hipMemcpyAsync(om.data(), h->omega, sizeof(double) * h->p, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    std::vector<double> cd((size_t)(2 * kScreen));
+    int64_t pos = 0, cool = 0, cool_len = kScreen;
+    while (pos < m) {
+        if (cool > 0) {   // unscreened stretch: whole Gram blocks
+            const int mm = (int)std::min<int64_t>({(int64_t)h->cap, m - pos, std::max<int64_t>(cool, B)});
+            CHK(run_chunk(h, idx0 + pos, mm, maxH));
+            pos += mm; cool -= mm;
+            continue;
+        }
+        const int S = (int)std::min<int64_t>(kScreen, m - pos);
+        std::memcpy(h->h_idx, idx0 + pos, sizeof(int64_t) * (size_t)S);
+        HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)S, hipMemcpyHostToDevice, h->stream));
+        CHK(col_dots(h, 0, S, h->r, false, h->d_idx));
+        HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * S, hipMemcpyDeviceToHost, h->stream));
+        double rnorm = 0.0;
+        if (h->loss == CDH_SQRT) {
+            CHK(resid_moments_dev(h));
+            HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->loss == CDH_SQRT) rnorm = std::sqrt(h->h_red[1]);
+        int hit = S;
+        for (int i = 0; i < S; ++i) {
+            const int64_t k = idx0[pos + i];
+            const double b = cd[(size_t)(2 * i)];
+            const double w = h->has_omega ? om[(size_t)k] : 1.0;
+            const double thr = (h->loss == CDH_SQRT ? lam * w * rnorm : lam * nt * w) * (1.0 - 1e-9);
+            // a zero column (a == 0) goes to the exact path too: the reference turns it into NaN
+            if (h->x.get(k) != 0.0 || !(std::fabs(b) <= thr) || !(cd[(size_t)(2 * i + 1)] > 0.0)) { hit = i; break; }
+        }
+        // visits [pos, pos + hit) are settled: h = 0; replay what the reference's SparseIterate
+        // would have seen (LS: x[k] += b/a stores a slot when b != 0, cdprox! zeroes it)
+        for (int i = 0; i < hit; ++i) {
+            const int64_t k = idx0[pos + i];
+            if (h->loss != CDH_SQRT && cd[(size_t)(2 * i)] != 0.0) h->x.set(k, 1.0);
+            h->x.set(k, 0.0);
+        }
+        pos += hit;
+        if (hit < S) {
+            const int mm = (int)std::min<int64_t>(std::max(B, 1), m - pos);
+            CHK(run_chunk(h, idx0 + pos, mm, maxH));
+            pos += mm;
+            cool = cool_len; cool_len = std::min<int64_t>(cool_len * 2, m);
+        } else {
+            cool_len = kScreen;
+        }
+    }
+    return CDH_OK;
+}
+
+// _cdPass! (coordinate_descent.jl:94-110)
+int32_t run_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, bool screen = false) {
     *maxH = 0.0;
-    for (int64_t off = 0; off < m; off += h->cap) {
-        const int mm = (int)std::min<int64_t>(h->cap, m - off);
-        CHK(run_chunk(h, idx0 + off, mm, maxH));
+    if (screen && h->screening && !h->has_w && m >= 2 * kScreen && h->x.nnz() * 4 <= h->p) {
+        CHK(screened_full_pass(h, idx0, m, maxH));
+    } else {
+        for (int64_t off = 0; off < m; off += h->cap) {
+            const int mm = (int)std::min<int64_t>(h->cap, m - off);
+            CHK(run_chunk(h, idx0 + off, mm, maxH));
+        }
     }
     h->x.dropzeros();
     return CDH_OK;
@@ -453,7 +530,7 @@ int32_t solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched, cd
         const bool full = converged;
         sched.next_pass(h->x, full, visit);
         double maxH = 0.0;
-        if (!visit.empty()) CHK(run_pass(h, visit.data(), (int64_t)visit.size(), &maxH));
+        if (!visit.empty()) CHK(run_pass(h, visit.data(), (int64_t)visit.size(), &maxH, full));
         else h->x.dropzeros();
         st->passes += 1; st->visits += (int64_t)visit.size(); st->maxH = maxH;
         if (full) st->full_passes += 1;
@@ -971,6 +1048,8 @@ int32_t cdh_set_sweep_mode(cdh_handle h, int32_t mode, int32_t block) {
     if (mode == CDH_SWEEP_BLOCK) h->blockB = block;
     return CDH_OK;
 }
+
+int32_t cdh_set_screening(cdh_handle h, int32_t on) { h->screening = on != 0; return CDH_OK; }
 
 int32_t cdh_set_use_graph(cdh_handle h, int32_t on) { h->use_graph = on != 0; return CDH_OK; }
 

@@ -648,7 +648,8 @@ __global__ __launch_bounds__(kBlock) void k_init_resid(const T* __restrict__ X, 
 
 // ---------------------------------------------------------------------------------
 // Batched column dots (GEMV-T shape): block (chunk, group) handles kColGroup consecutive
-// columns j0 + group*kColGroup + i over one row chunk, reading r (and w) ONCE for the group:
+// columns j0 + group*kColGroup + i (or, with `cols`, the list entries cols[j0 + ...]) over one
+// row chunk, reading r (and w) ONCE for the group:
 //   out0 = sum w x r,  out1 = sum w x^2      (w = 1 when w == nullptr)
 // partials[((group * nchunks + chunk) * kColGroup + i) * 2 + {0,1}], reduced by k_col_dots_reduce.
 // ---------------------------------------------------------------------------------
@@ -658,6 +659,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_col_dots(const T* __restrict__ X, int64_t ld,
                                                      int64_t nvec, const T* __restrict__ w,
                                                      const T* __restrict__ r, int64_t j0, int ncols,
+                                                     const int64_t* __restrict__ cols,
                                                      double* __restrict__ partials) {
     using V = typename VecOf<T>::V;
     constexpr int NV = VecOf<T>::N;
@@ -665,8 +667,10 @@ __global__ __launch_bounds__(kBlock) void k_col_dots(const T* __restrict__ X, in
     const int c0 = blockIdx.y * kColGroup;
     const V* cv[kColGroup];
 #pragma unroll
-    for (int i = 0; i < kColGroup; ++i)   // columns past the end alias the group's first (discarded)
-        cv[i] = reinterpret_cast<const V*>(X + (j0 + (c0 + i < ncols ? c0 + i : c0)) * ld);
+    for (int i = 0; i < kColGroup; ++i) {  // columns past the end alias the group's first (discarded)
+        const int64_t ci = j0 + (c0 + i < ncols ? c0 + i : c0);
+        cv[i] = reinterpret_cast<const V*>(X + (cols ? cols[ci] : ci) * ld);   // list entry or column
+    }
     const V* rv = reinterpret_cast<const V*>(r);
     const V* wv = reinterpret_cast<const V*>(w);
     double acc[2 * kColGroup];

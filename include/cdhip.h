@@ -179,6 +179,11 @@ int32_t cdh_set_sweep_mode(cdh_handle h, int32_t mode, int32_t block);
  * handle already holds keeps the carried residual (LassoPath, lasso.jl:250-252: 100 rebuilds
  * of n x nnz work saved); the difference is rounding only. */
 int32_t cdh_set_reuse_residual(cdh_handle h, int32_t on);
+/* Full passes of cdh_solve / cdh_coordinate_descent over a sparse iterate are screened by
+ * default: runs of visits that provably leave beta and r unchanged (beta_k == 0 and |X_k'r|
+ * below the threshold) are settled from one dots-only pass over their columns; the iterates
+ * are the same as visiting one by one.  cdh_pass never screens. */
+int32_t cdh_set_screening(cdh_handle h, int32_t on);
 /* Replay each pass from a captured hipGraph instead of individual launches. */
 int32_t cdh_set_use_graph(cdh_handle h, int32_t on);
 /* Multi-process row sharding: rank 0 calls cdh_comm_unique_id, broadcasts the

@@ -487,3 +487,53 @@ def test_full_size_properties_cfg2():
     x2 = cd.SparseIterate(p)
     cd.coordinateDescent_(x2, f, g, cd.CDOptions(maxIter=100, optTol=1e-11, randomize=False))
     np.testing.assert_allclose(x2.dense(), xb, rtol=0, atol=BETA_TOL)
+
+
+# ---- screened full passes: same iterates, same bookkeeping, fewer bytes ---------------------------
+@pytest.mark.parametrize("loss", ["ls", "wl1", "sqrt"])
+@pytest.mark.parametrize("rand", [False, True], ids=["ordered", "random"])
+def test_screened_full_passes_match_oracle_and_unscreened(loss, rand):
+    rng, X, Y = _problem(41, 2500, 700, 12, noise=1.0)
+    om = (rng.random(700) + 0.5) if loss == "wl1" else None
+    lam = 3.2 if loss == "sqrt" else 0.08
+    o = dict(maxIter=2000, optTol=1e-12, randomize=rand, seed=11)
+    cls, ocls = (cd.CDSqrtLassoLoss, O.CDSqrtLassoLoss) if loss == "sqrt" else (cd.CDLeastSquaresLoss, O.CDLeastSquaresLoss)
+    xo = O.SparseIterate(700)
+    fo = ocls(Y, X)
+    sto = O.coordinateDescent_(xo, fo, O.ProxL1(lam, om), O.CDOptions(**o))
+    outs = []
+    for screen in (True, False):
+        f = cls(Y, X)
+        f.set_sweep_mode("block", 16)
+        f.set_screening(screen)
+        x = cd.SparseIterate(700)
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(**o))
+        # warm start from the solution at a smaller lambda: first full pass over a sparse iterate
+        cd.coordinateDescent_(x, f, cd.ProxL1(0.7 * lam, om), cd.CDOptions(**o))
+        outs.append((x.dense(), x.nzval2ind.tolist(), f.last_stats["passes"], f.r))
+    O.coordinateDescent_(xo, fo, O.ProxL1(0.7 * lam, om), O.CDOptions(**o))
+    assert 0 < xo.nnz < 700 // 4
+    for beta, sup, passes, r in outs:
+        np.testing.assert_allclose(beta, xo.dense(), rtol=0, atol=BETA_TOL)
+        assert sup == xo.nzval2ind.tolist()          # same support ORDER: same bookkeeping replayed
+        np.testing.assert_allclose(r, fo.r, rtol=0, atol=1e-9)
+    assert outs[0][2] == outs[1][2]                  # same number of passes with and without
+
+
+def test_zero_column_is_handled_like_the_oracle():
+    """A zero column makes x[k] += b/a a 0/0 (the reference has no guard).  What
+    ProximalBase's cdprox! then does with the NaN is not pinned by any reference test; oracle and
+    product both soft-threshold it to 0 (comparisons with NaN are false).  Screening sends such a
+    column to the exact path so both modes agree with the oracle."""
+    rng, X, Y = _problem(42, 400, 300, 5)
+    X[:, 200] = 0.0
+    xo = O.SparseIterate(300)
+    O.coordinateDescent_(xo, O.CDLeastSquaresLoss(Y, X), O.ProxL1(0.2), O.CDOptions(maxIter=50, optTol=1e-12, randomize=False))
+    for screen in (True, False):
+        f = cd.CDLeastSquaresLoss(Y, X)
+        f.set_sweep_mode("block", 16)
+        f.set_screening(screen)
+        x = cd.SparseIterate(300)
+        cd.coordinateDescent_(x, f, cd.ProxL1(0.2), cd.CDOptions(maxIter=50, optTol=1e-12, randomize=False))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert x.dense()[200] == xo.dense()[200] == 0.0
