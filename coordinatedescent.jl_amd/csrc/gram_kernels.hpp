@@ -101,7 +101,10 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
     double qacc = 0.0;
 
     const int64_t nchunks = (nvec + 63) >> 6;
-    for (int64_t ch = (int64_t)blockIdx.x * kGramWaves + wave; ch < nchunks;
+    // chunk -> (block, wave): the block index runs fastest, so consecutive chunks go to different
+    // blocks and no block gets more than one chunk above any other (a block-major split would
+    // hand the last partial round to a few blocks, four chunks each: ~10 % tail at 1e6 rows)
+    for (int64_t ch = (int64_t)wave * gridDim.x + blockIdx.x; ch < nchunks;
          ch += (int64_t)gridDim.x * kGramWaves) {
         const int64_t v0 = ch << 6;
         // ---- phase A (coalesced): r' = r - sum_i h_i X_prev,i on this wave's 64 vectors -------
