@@ -241,7 +241,7 @@ int32_t rebuild_residual(cdh_handle h) {
 }
 
 // ---- one chunk of a pass: visits idx0[0..m) -------------------------------------------
-template <typename T, int B> void launch_block_chunk(cdh_handle h, int m) {
+template <typename T, int B> int32_t launch_block_chunk(cdh_handle h, int m) {
     constexpr int NREC = BlockRec<B>::N;
     const int G = h->block_grid;
     int nprev = 0;
@@ -261,7 +261,7 @@ template <typename T, int B> void launch_block_chunk(cdh_handle h, int m) {
             hipLaunchKernelGGL((k_block_finalize<B, false>), dim3(1), dim3(1024), 0, h->stream,
                                h->d_partials, G, nb, h->d_ctrl, h->beta, h->omega, h->d_idx, h->d_hs,
                                h->d_newval, h->d_touched, pos0, h->d_red);
-            allreduce(h, h->d_red, NREC);
+            CHK(allreduce(h, h->d_red, NREC));
             hipLaunchKernelGGL((k_block_scalar<B>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb,
                                h->d_ctrl, h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval,
                                h->d_touched, pos0);
@@ -271,10 +271,11 @@ template <typename T, int B> void launch_block_chunk(cdh_handle h, int m) {
     const int last0 = ((m - 1) / B) * B;
     hipLaunchKernelGGL((k_block_axpy<T, B>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
                        h->nvec, (T*)h->r, h->d_idx, h->d_hs, last0, m - last0);
+    return CDH_OK;
 }
 
 // wide blocks (B = 16 / 32): MFMA-accumulated Gram kernel + two-stage reduction
-template <typename T, int NG> void launch_gram_chunk(cdh_handle h, int m) {
+template <typename T, int NG> int32_t launch_gram_chunk(cdh_handle h, int m) {
     using R = GramRec<NG>;
     constexpr int B = R::B;
     // blocks per CU follow the kernel's register footprint (2 waves per SIMD for both widths)
@@ -291,7 +292,7 @@ template <typename T, int NG> void launch_gram_chunk(cdh_handle h, int m) {
                                (const T*)h->X, h->ld, h->nvec, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
                                h->d_partials);
         hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + 3) / 4), dim3(256), 0, h->stream, h->d_partials, G, R::N, h->d_red);  // one value per wave
-        allreduce(h, h->d_red, R::N);
+        CHK(allreduce(h, h->d_red, R::N));
         hipLaunchKernelGGL((k_gram_scalar<NG>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb, h->chunk_dup ? 1 : 0, h->d_ctrl,
                            h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos0);
         nprev = nb;
@@ -299,13 +300,14 @@ template <typename T, int NG> void launch_gram_chunk(cdh_handle h, int m) {
     const int last0 = ((m - 1) / B) * B;
     hipLaunchKernelGGL(k_multi_axpy<T>, dim3(h->step_grid), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
                        h->nvec, (T*)h->r, h->d_idx, h->d_hs, last0, m - last0);
+    return CDH_OK;
 }
 
 inline int NGgrid(cdh_handle h, int NG) {
     return NG >= 2 ? balanced_grid(h->gram_units, (int64_t)h->cus * h->gram32_per_cu) : h->gram_grid;
 }
 
-template <typename T> void launch_coord_chunk(cdh_handle h, int m) {
+template <typename T> int32_t launch_coord_chunk(cdh_handle h, int m) {
     const int G = h->step_grid;
     for (int pos = 0; pos < m; ++pos) {
         if (h->has_w)
@@ -325,13 +327,14 @@ template <typename T> void launch_coord_chunk(cdh_handle h, int m) {
             hipLaunchKernelGGL(k_finalize<false>, dim3(1), dim3(kBlock), 0, h->stream, h->d_partials, G,
                                h->d_ctrl, h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched,
                                pos, h->d_red);
-            allreduce(h, h->d_red, 4);
+            CHK(allreduce(h, h->d_red, 4));
             hipLaunchKernelGGL(k_scalar_update, dim3(1), dim3(64), 0, h->stream, h->d_red, h->d_ctrl,
                                h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos);
         }
     }
     hipLaunchKernelGGL(k_axpy<T>, dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld, h->nvec,
                        (T*)h->r, h->d_idx, h->d_hs, m);
+    return CDH_OK;
 }
 
 int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
@@ -354,14 +357,13 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     auto enqueue = [&]() {
         return dispatch(h, [&](auto* t) {
             using T = std::remove_pointer_t<decltype(t)>;
-            if (!blocked) launch_coord_chunk<T>(h, m);
-            else if (h->blockB == 64) launch_gram_chunk<T, 4>(h, m);
-            else if (h->blockB == 32) launch_gram_chunk<T, 2>(h, m);
-            else if (h->blockB == 16) launch_gram_chunk<T, 1>(h, m);
-            else if (h->blockB == 8) launch_block_chunk<T, 8>(h, m);
-            else if (h->blockB == 4) launch_block_chunk<T, 4>(h, m);
-            else launch_block_chunk<T, 2>(h, m);
-            return CDH_OK;
+            if (!blocked) return launch_coord_chunk<T>(h, m);
+            if (h->blockB == 64) return launch_gram_chunk<T, 4>(h, m);
+            if (h->blockB == 32) return launch_gram_chunk<T, 2>(h, m);
+            if (h->blockB == 16) return launch_gram_chunk<T, 1>(h, m);
+            if (h->blockB == 8) return launch_block_chunk<T, 8>(h, m);
+            if (h->blockB == 4) return launch_block_chunk<T, 4>(h, m);
+            return launch_block_chunk<T, 2>(h, m);
         });
     };
     // hipGraph replay: the launch sequence of an m-visit chunk depends only on (m, mode, B) --
@@ -376,8 +378,9 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
         if (!exec) {
             hipGraph_t graph = nullptr;
             HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            enqueue();
+            const int32_t erc = enqueue();
             HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
+            if (erc != CDH_OK) { (void)hipGraphDestroy(graph); return erc; }
             HIPCHK(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             HIPCHK(h, hipGraphDestroy(graph));
             if (h->graphs.size() >= 32) {  // bounded cache: drop the oldest
@@ -752,7 +755,7 @@ int32_t cdh_set_obs_weights(cdh_handle h, const void* host_w) {
     return CDH_OK;
 }
 
-int32_t cdh_generate(cdh_handle h, uint64_t seed, int64_t s, double noise, double* out_beta_star) {
+static int32_t cdh_generate_impl(cdh_handle h, uint64_t seed, int64_t s, double noise, double* out_beta_star) {
     if (s < 0 || s > h->p) return fail(h, CDH_BAD_ARG, "need 0 <= s <= p");
     HIPCHK(h, hipSetDevice(h->device));
     // planted coefficients: beta*_j = z_j (1 + u_j) (benchmark/cd_bench.jl:14), stream 2
@@ -792,7 +795,7 @@ int32_t cdh_generate(cdh_handle h, uint64_t seed, int64_t s, double noise, doubl
     return CDH_OK;
 }
 
-int32_t cdh_set_penalty(cdh_handle h, double lambda0, const double* omega, int64_t n_omega) {
+static int32_t cdh_set_penalty_impl(cdh_handle h, double lambda0, const double* omega, int64_t n_omega) {
     HIPCHK(h, hipSetDevice(h->device));
     if (omega) {
         if (n_omega != h->p) return fail(h, CDH_DIM_MISMATCH, "length(g.lambda) != numCoordinates(f)");
@@ -810,7 +813,7 @@ int32_t cdh_set_penalty(cdh_handle h, double lambda0, const double* omega, int64
 
 int32_t cdh_num_coordinates(cdh_handle h, int64_t* out) { *out = h->p; return CDH_OK; }
 
-int32_t cdh_set_iterate(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t* idx1, const double* val) {
+static int32_t cdh_set_iterate_impl(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t* idx1, const double* val) {
     if (x_length != h->p) return fail(h, CDH_DIM_MISMATCH, "numCoordinates(x) != numCoordinates(f)");
     if (nnz < 0 || nnz > h->p) return fail(h, CDH_BAD_ARG, "nnz out of range");
     for (int64_t i = 0; i < nnz; ++i)
@@ -830,12 +833,12 @@ int32_t cdh_set_iterate(cdh_handle h, int64_t x_length, int64_t nnz, const int64
     return CDH_OK;
 }
 
-int32_t cdh_initialize(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t* idx1, const double* val) {
-    CHK(cdh_set_iterate(h, x_length, nnz, idx1, val));
+static int32_t cdh_initialize_impl(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t* idx1, const double* val) {
+    CHK(cdh_set_iterate_impl(h, x_length, nnz, idx1, val));
     return rebuild_residual(h);
 }
 
-int32_t cdh_gradient(cdh_handle h, int64_t k1, double* out) {
+static int32_t cdh_gradient_impl(cdh_handle h, int64_t k1, double* out) {
     if (k1 < 1 || k1 > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
     HIPCHK(h, hipSetDevice(h->device));
     CHK(col_dots(h, k1 - 1, 1, h->r, h->loss == CDH_WLS));
@@ -857,7 +860,7 @@ int32_t cdh_gradient(cdh_handle h, int64_t k1, double* out) {
     return CDH_OK;
 }
 
-int32_t cdh_descend(cdh_handle h, int64_t k1, double* out_h) {
+static int32_t cdh_descend_impl(cdh_handle h, int64_t k1, double* out_h) {
     if (k1 < 1 || k1 > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t k0 = k1 - 1;
@@ -871,12 +874,12 @@ int32_t cdh_descend(cdh_handle h, int64_t k1, double* out_h) {
     return CDH_OK;
 }
 
-int32_t cdh_lambda_max(cdh_handle h, double* out) {
+static int32_t cdh_lambda_max_impl(cdh_handle h, double* out) {
     HIPCHK(h, hipSetDevice(h->device));
     return lambda_max(h, out);
 }
 
-int32_t cdh_pass(cdh_handle h, int64_t m, const int64_t* idx1, double* out_maxH) {
+static int32_t cdh_pass_impl(cdh_handle h, int64_t m, const int64_t* idx1, double* out_maxH) {
     if (m < 0) return fail(h, CDH_BAD_ARG, "m < 0");
     HIPCHK(h, hipSetDevice(h->device));
     std::vector<int64_t> idx0((size_t)m);
@@ -891,7 +894,7 @@ int32_t cdh_pass(cdh_handle h, int64_t m, const int64_t* idx1, double* out_maxH)
     return CDH_OK;
 }
 
-int32_t cdh_solve(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
+static int32_t cdh_solve_impl(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
     HIPCHK(h, hipSetDevice(h->device));
     cdh_stats st{};
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
@@ -900,7 +903,7 @@ int32_t cdh_solve(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
     return rc;
 }
 
-int32_t cdh_coordinate_descent(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
+static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
     HIPCHK(h, hipSetDevice(h->device));
     cdh_stats st{};
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
@@ -956,7 +959,7 @@ int32_t cdh_get_residual(cdh_handle h, void* out_n_local) {
     return CDH_OK;
 }
 
-int32_t cdh_col_rms(cdh_handle h, double* out_p) {
+static int32_t cdh_col_rms_impl(cdh_handle h, double* out_p) {
     HIPCHK(h, hipSetDevice(h->device));
     CHK(col_dots(h, 0, h->p, h->r, false));
     std::vector<double> cd((size_t)(2 * h->p));
@@ -966,7 +969,7 @@ int32_t cdh_col_rms(cdh_handle h, double* out_p) {
     return CDH_OK;
 }
 
-int32_t cdh_xt_r(cdh_handle h, double* out_p) {
+static int32_t cdh_xt_r_impl(cdh_handle h, double* out_p) {
     HIPCHK(h, hipSetDevice(h->device));
     CHK(col_dots(h, 0, h->p, h->r, false));
     std::vector<double> cd((size_t)(2 * h->p));
@@ -976,7 +979,7 @@ int32_t cdh_xt_r(cdh_handle h, double* out_p) {
     return CDH_OK;
 }
 
-int32_t cdh_gram(cdh_handle h, int64_t m, const int64_t* idx1, double* out_G, double* out_c, double* out_q) {
+static int32_t cdh_gram_impl(cdh_handle h, int64_t m, const int64_t* idx1, double* out_G, double* out_c, double* out_q) {
     if (m < 1 || m > 64) return fail(h, CDH_BAD_ARG, "need 1 <= m <= 64 columns");
     for (int64_t i = 0; i < m; ++i)
         if (idx1[i] < 1 || idx1[i] > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
@@ -1021,7 +1024,7 @@ int32_t cdh_resid_moments(cdh_handle h, double* out_sum, double* out_sumsq) {
     return CDH_OK;
 }
 
-int32_t cdh_objective(cdh_handle h, double* out) {
+static int32_t cdh_objective_impl(cdh_handle h, double* out) {
     HIPCHK(h, hipSetDevice(h->device));
     CHK(resid_moments_dev(h));
     HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1092,6 +1095,82 @@ int32_t cdh_profile_end(cdh_handle h, double* out_ms, int64_t* out_launches, dou
     if (out_launches) *out_launches = h->prof_launches;
     if (out_algorithmic_bytes) *out_algorithmic_bytes = h->prof_bytes;
     return CDH_OK;
+}
+
+// ---- exception firewall: nothing may unwind across the C ABI ----------------------------------
+#define CDH_CATCH(h)                                                              \
+    catch (const std::bad_alloc&) { return fail((h), CDH_OOM, "host allocation failed"); } \
+    catch (const std::exception& e) { return fail((h), CDH_BAD_ARG, e.what()); }  \
+    catch (...) { return fail((h), CDH_BAD_ARG, "unknown C++ exception"); }
+
+int32_t cdh_pass(cdh_handle h, int64_t m, const int64_t* idx1, double* out_maxH) {
+    try { return cdh_pass_impl(h, m, idx1, out_maxH); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_solve(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
+    try { return cdh_solve_impl(h, opt, out); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_coordinate_descent(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
+    try { return cdh_coordinate_descent_impl(h, opt, out); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_initialize(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t* idx1, const double* val) {
+    try { return cdh_initialize_impl(h, x_length, nnz, idx1, val); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_set_iterate(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t* idx1, const double* val) {
+    try { return cdh_set_iterate_impl(h, x_length, nnz, idx1, val); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_lambda_max(cdh_handle h, double* out) {
+    try { return cdh_lambda_max_impl(h, out); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_col_rms(cdh_handle h, double* out_p) {
+    try { return cdh_col_rms_impl(h, out_p); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_xt_r(cdh_handle h, double* out_p) {
+    try { return cdh_xt_r_impl(h, out_p); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_gram(cdh_handle h, int64_t m, const int64_t* idx1, double* out_G, double* out_c, double* out_q) {
+    try { return cdh_gram_impl(h, m, idx1, out_G, out_c, out_q); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_generate(cdh_handle h, uint64_t seed, int64_t s, double noise, double* out_beta_star) {
+    try { return cdh_generate_impl(h, seed, s, noise, out_beta_star); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_objective(cdh_handle h, double* out) {
+    try { return cdh_objective_impl(h, out); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_gradient(cdh_handle h, int64_t k1, double* out) {
+    try { return cdh_gradient_impl(h, k1, out); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_descend(cdh_handle h, int64_t k1, double* out_h) {
+    try { return cdh_descend_impl(h, k1, out_h); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_set_penalty(cdh_handle h, double lambda0, const double* omega, int64_t n_omega) {
+    try { return cdh_set_penalty_impl(h, lambda0, omega, n_omega); }
+    CDH_CATCH(h)
 }
 
 }  // extern "C"
