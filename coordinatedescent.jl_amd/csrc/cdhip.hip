@@ -280,16 +280,17 @@ template <typename T, int NG> int32_t launch_gram_chunk(cdh_handle h, int m) {
     constexpr int B = R::B;
     // blocks per CU follow the kernel's register footprint (2 waves per SIMD for both widths)
     const int G = NG >= 2 ? balanced_grid(h->gram_units, (int64_t)h->cus * h->gram32_per_cu) : h->gram_grid;
+    const T* wts = h->has_w ? (const T*)h->w : (const T*)nullptr;
     int nprev = 0;
     for (int pos0 = 0; pos0 < m; pos0 += B) {
         const int nb = std::min(B, m - pos0);
         if (h->nt)
             hipLaunchKernelGGL((k_gramstep<T, NG, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
-                               (const T*)h->X, h->ld, h->nvec, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
+                               (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
                                h->d_partials);
         else
             hipLaunchKernelGGL((k_gramstep<T, NG, false>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
-                               (const T*)h->X, h->ld, h->nvec, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
+                               (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
                                h->d_partials);
         hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + 3) / 4), dim3(256), 0, h->stream, h->d_partials, G, R::N, h->d_red);  // one value per wave
         CHK(allreduce(h, h->d_red, R::N));
@@ -353,7 +354,8 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     h->ctrl.domain_error = 0;
     CHK(upload_ctrl(h));
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    const bool blocked = (h->mode == CDH_SWEEP_BLOCK) && !h->has_w;
+    // observation weights: the wide-block kernel carries them; the vector-ALU blocks (B <= 8) do not
+    const bool blocked = (h->mode == CDH_SWEEP_BLOCK) && (!h->has_w || h->blockB >= 16);
     auto enqueue = [&]() {
         return dispatch(h, [&](auto* t) {
             using T = std::remove_pointer_t<decltype(t)>;
@@ -992,7 +994,8 @@ static int32_t cdh_gram_impl(cdh_handle h, int64_t m, const int64_t* idx1, doubl
     CHK(dispatch(h, [&](auto* t) {
         using T = std::remove_pointer_t<decltype(t)>;
         hipLaunchKernelGGL((k_gramstep<T, 4, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
-                           (const T*)h->X, h->ld, h->nvec, (T*)h->r, h->d_idx, h->d_hs, 0, (int)m, 0, h->d_partials);
+                           (const T*)h->X, h->ld, h->nvec, (const T*)nullptr, (T*)h->r, h->d_idx, h->d_hs, 0, (int)m, 0,
+                           h->d_partials);
         return CDH_OK;
     }));
     hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + 3) / 4), dim3(256), 0, h->stream, h->d_partials, G, R::N, h->d_red);

@@ -48,13 +48,14 @@ constexpr int kGramWaves = 4;  // waves per block
 
 template <typename T, int NG, bool NT_>
 __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
-    const T* __restrict__ X, int64_t ld, int64_t nvec, T* __restrict__ r,
+    const T* __restrict__ X, int64_t ld, int64_t nvec, const T* __restrict__ w, T* __restrict__ r,
     const int64_t* __restrict__ idx, const double* __restrict__ hs, int pos0, int nb, int nprev,
     double* __restrict__ partials) {
     using V = typename VecOf<T>::V;
     constexpr int NV = VecOf<T>::N;
     using R = GramRec<NG>;
     constexpr int B = R::B;
+    __shared__ V s_w[kGramWaves][64];            // observation weights of the chunk (CDWeightedLSLoss)
     __shared__ V s_r[kGramWaves][64];            // r' of the wave's current 64-vector chunk
     __shared__ double s_hp[B];
     __shared__ int64_t s_kp[B];
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
         for (int e = 0; e < NV; ++e) qacc = fma((double)rr[e], (double)rr[e], qacc);
         __builtin_amdgcn_wave_barrier();
         s_r[wave][lane] = rr;
+        if (w) s_w[wave][lane] = inb ? reinterpret_cast<const V*>(w)[jv] : vzero((V*)nullptr);
         __builtin_amdgcn_wave_barrier();
         // ---- phase B: tiles += X_I' X_J, X_I' r' over the chunk's rows, in UH-sized groups of
         // fragment loads (16/NG vector rows at a time so the kernel fits 2 waves per SIMD: the
@@ -157,19 +159,27 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
 #pragma unroll
             for (int u = 0; u < UH; ++u) {
                 const V rf = s_r[wave][4 * (u0 + u) + g];
+                V wf = rf;
+                if (w) wf = s_w[wave][4 * (u0 + u) + g];
 #pragma unroll
                 for (int e = 0; e < NV; ++e) {
-                    double a[NG];
+                    // A operands carry the observation weight (G = X'WX, c = X'Wr:
+                    // cd_differentiable_function.jl:177-182); B operands do not
+                    double a[NG], aw[NG];
+                    const double we = w ? (double)wf[e] : 1.0;
 #pragma unroll
-                    for (int grp = 0; grp < NG; ++grp) a[grp] = (double)xf[u][grp][e];
+                    for (int grp = 0; grp < NG; ++grp) {
+                        a[grp] = (double)xf[u][grp][e];
+                        aw[grp] = a[grp] * we;
+                    }
                     const double rb = (double)rf[e];
 #pragma unroll
                     for (int gi = 0; gi < NG; ++gi) {
 #pragma unroll
                         for (int gj = gi; gj < NG; ++gj)
                             tile[R::tile(gi, gj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-                                a[gi], a[gj], tile[R::tile(gi, gj)], 0, 0, 0);
-                        ctile[gi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gi], rb, ctile[gi], 0, 0, 0);
+                                aw[gi], a[gj], tile[R::tile(gi, gj)], 0, 0, 0);
+                        ctile[gi] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[gi], rb, ctile[gi], 0, 0, 0);
                     }
                 }
             }

@@ -248,14 +248,19 @@ def test_lasso_path(standardize):  # :220-288
     assert short.lambdapath == [0.3] and len(short.betapath) == 1
 
 
-def test_weighted_ls_loss_matches_oracle():
-    rng, X, Y = _problem(12, 300, 20, 5)
-    w = rng.random(300) + 0.5
+@pytest.mark.parametrize("mode", [MODES[0], MODES[1], MODES[4], MODES[5]], ids=lambda m: f"{m[0]}{m[1]}")
+def test_weighted_ls_loss_matches_oracle(mode):
+    rng, X, Y = _problem(12, 3001, 45, 5)
+    w = rng.random(3001) + 0.5
     o = dict(maxIter=5000, optTol=1e-12, randomize=False)
-    x, xo = cd.SparseIterate(20), O.SparseIterate(20)
-    cd.coordinateDescent_(x, cd.CDWeightedLSLoss(Y, X, w), cd.ProxL1(0.05), cd.CDOptions(**o))
-    O.coordinateDescent_(xo, O.CDWeightedLSLoss(Y, X, w), O.ProxL1(0.05), O.CDOptions(**o))
+    x, xo = cd.SparseIterate(45), O.SparseIterate(45)
+    f, fo = cd.CDWeightedLSLoss(Y, X, w), O.CDWeightedLSLoss(Y, X, w)
+    _set_mode(f, mode)          # B = 8 has no weighted kernel: falls back to the per-coordinate sweep
+    cd.coordinateDescent_(x, f, cd.ProxL1(0.05), cd.CDOptions(**o))
+    st = O.coordinateDescent_(xo, fo, O.ProxL1(0.05), O.CDOptions(**o))
     np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+    np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-9)
+    assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"]
 
 
 # ---- fp32 storage (fp64 accumulation): loose, declared tolerance ------------------------------
