@@ -94,6 +94,12 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
     }
     V* __restrict__ rv = reinterpret_cast<V*>(r);
 
+    // fp32 storage: each chunk (256 rows) is accumulated by v_mfma_f32_16x16x4_f32 from zero and
+    // folded into the fp64 running tiles at the end of the chunk -- half the matrix-pipe time of
+    // converting to fp64 first, and each fp32 partial sum spans 256 rows only (far tighter than the
+    // reference's own Float32 running sums over all n rows).  Its D fragment has rows 4g + q
+    // where the fp64 instruction has g + 4q; the running tiles simply live in that layout.
+    constexpr bool F32 = sizeof(T) == 4;
     dvec4 tile[R::NT], ctile[NG];
 #pragma unroll
     for (int t = 0; t < R::NT; ++t) tile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
@@ -146,6 +152,13 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
         // fragment loads (16/NG vector rows at a time so the kernel fits 2 waves per SIMD: the
         // other wave's loads then overlap this wave's MFMA phase) ------------------------------------
         constexpr int UH = (NG == 4) ? 2 : 16 / NG;
+        fvec4 t32[R::NT], c32[NG];
+        if constexpr (F32) {
+#pragma unroll
+            for (int t = 0; t < R::NT; ++t) t32[t] = fvec4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NG; ++t) c32[t] = fvec4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int u0 = 0; u0 < 16; u0 += UH) {
             V xf[UH][NG];
@@ -165,6 +178,25 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
                 for (int e = 0; e < NV; ++e) {
                     // A operands carry the observation weight (G = X'WX, c = X'Wr:
                     // cd_differentiable_function.jl:177-182); B operands do not
+                    if constexpr (F32) {
+                        float a[NG], aw[NG];
+                        const float we = w ? (float)wf[e] : 1.f;
+#pragma unroll
+                        for (int grp = 0; grp < NG; ++grp) {
+                            a[grp] = (float)xf[u][grp][e];
+                            aw[grp] = a[grp] * we;
+                        }
+                        const float rb = (float)rf[e];
+#pragma unroll
+                        for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+                            for (int gj = gi; gj < NG; ++gj)
+                                t32[R::tile(gi, gj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    aw[gi], a[gj], t32[R::tile(gi, gj)], 0, 0, 0);
+                            c32[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[gi], rb, c32[gi], 0, 0, 0);
+                        }
+                        continue;
+                    }
                     double a[NG], aw[NG];
                     const double we = w ? (double)wf[e] : 1.0;
 #pragma unroll
@@ -184,6 +216,16 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
                 }
             }
         }
+        if constexpr (F32) {
+#pragma unroll
+            for (int t = 0; t < R::NT; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) tile[t][q4] += (double)t32[t][q4];
+#pragma unroll
+            for (int t = 0; t < NG; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) ctile[t][q4] += (double)c32[t][q4];
+        }
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -193,13 +235,13 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
 #pragma unroll
     for (int t = 0; t < R::NT; ++t) {
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) s_red[wave][(g + 4 * q4) * 16 + c] = tile[t][q4];
+        for (int q4 = 0; q4 < 4; ++q4) s_red[wave][(F32 ? 4 * g + q4 : g + 4 * q4) * 16 + c] = tile[t][q4];
         __syncthreads();
         {
             const int v = threadIdx.x;   // 256 threads, 256 tile elements
             double sum = 0.0;
 #pragma unroll
-            for (int w = 0; w < kGramWaves; ++w) sum += s_red[w][v];
+            for (int wv = 0; wv < kGramWaves; ++wv) sum += s_red[wv][v];
             partials[(int64_t)(t * 256 + v) * gridDim.x + blockIdx.x] = sum;
         }
         __syncthreads();
@@ -208,14 +250,14 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
 #pragma unroll
         for (int t = 0; t < NG; ++t)
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) s_red[wave][16 * t + g + 4 * q4] = ctile[t][q4];
+            for (int q4 = 0; q4 < 4; ++q4) s_red[wave][16 * t + (F32 ? 4 * g + q4 : g + 4 * q4)] = ctile[t][q4];
     }
     if (lane == 0) s_red[wave][B] = qacc;
     __syncthreads();
     for (int v = threadIdx.x; v < B + 1; v += blockDim.x) {
         double sum = 0.0;
 #pragma unroll
-        for (int w = 0; w < kGramWaves; ++w) sum += s_red[w][v];
+        for (int wv = 0; wv < kGramWaves; ++wv) sum += s_red[wv][v];
         partials[(int64_t)(R::OFF_C + v) * gridDim.x + blockIdx.x] = sum;
     }
 }
