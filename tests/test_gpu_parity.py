@@ -542,3 +542,26 @@ def test_zero_column_is_handled_like_the_oracle():
         cd.coordinateDescent_(x, f, cd.ProxL1(0.2), cd.CDOptions(maxIter=50, optTol=1e-12, randomize=False))
         np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
         assert x.dense()[200] == xo.dense()[200] == 0.0
+
+
+# ---- large p, short columns: visit lists longer than one chunk of visit state ---------------------
+@pytest.mark.parametrize("mode", [MODES[0], MODES[4], MODES[6]], ids=lambda m: f"{m[0]}{m[1]}")
+def test_wide_problem_and_chunked_visit_lists(mode):
+    rng = np.random.default_rng(77)
+    n, p = 96, 6000
+    X = np.asfortranarray(rng.standard_normal((n, p)))
+    Y = X[:, :5] @ rng.standard_normal(5) + 0.1 * rng.standard_normal(n)
+    f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+    _set_mode(f, mode)
+    g, go = cd.ProxL1(0.3), O.ProxL1(0.3)
+    x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+    cd.initialize_(f, x)
+    O.initialize_(fo, xo)
+    visit = list(range(1, p + 1)) + list(range(p, 0, -1)) + [7, 7, 9]     # 2p + 3 visits > one chunk
+    mh, mho = cd.cdPass_(x, f, g, visit), O.cdPass_(xo, fo, go, visit)
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(mh, mho, rtol=1e-9)
+    assert x.nzval2ind.tolist() == xo.nzval2ind.tolist()
+    cd.coordinateDescent_(x, f, g, cd.CDOptions(maxIter=3000, optTol=1e-12, randomize=False))
+    O.coordinateDescent_(xo, fo, go, O.CDOptions(maxIter=3000, optTol=1e-12, randomize=False))
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
