@@ -47,7 +47,7 @@ template <int NG> struct GramRec {
 constexpr int kGramWaves = 4;  // waves per block
 
 template <typename T, int NG, bool NT_>
-__global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
+__global__ __launch_bounds__(64 * kGramWaves, (NG == 4) ? 2 : 3) void k_gramstep(
     const T* __restrict__ X, int64_t ld, int64_t nvec, const T* __restrict__ w, T* __restrict__ r,
     const int64_t* __restrict__ idx, const double* __restrict__ hs, int pos0, int nb, int nprev,
     double* __restrict__ partials) {
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
     __shared__ double s_hp[B];
     __shared__ int64_t s_kp[B];
     __shared__ double s_red[kGramWaves][256];    // end-of-kernel cross-wave reduction, per tile
+    __shared__ double s_q[kGramWaves];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
 
@@ -100,11 +101,18 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
     // reference's own Float32 running sums over all n rows).  Its D fragment has rows 4g + q
     // where the fp64 instruction has g + 4q; the running tiles simply live in that layout.
     constexpr bool F32 = sizeof(T) == 4;
+    // X_I'r: for B >= 32 it is NOT taken on the matrix pipe -- as an MFMA it broadcasts r over 16
+    // columns and wastes 15/16 of the instruction; one vector FMA per element into a per-lane
+    // partial (summed over the lane's row group at the end) leaves the pipe to the Gram tiles
+    // (5 -> 3 MFMAs per 4 rows at B = 32: measured -4 % at 1.25e6 rows).  At B = 16 the pipe has
+    // room and the MFMA form measured ~5 % faster at 1e7 rows, so it keeps one c tile.
+    constexpr bool CV = (NG >= 2);
     dvec4 tile[R::NT], ctile[NG];
+    double cacc[NG];
 #pragma unroll
     for (int t = 0; t < R::NT; ++t) tile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int t = 0; t < NG; ++t) ctile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < NG; ++t) { cacc[t] = 0.0; ctile[t] = dvec4{0.0, 0.0, 0.0, 0.0}; }
     double qacc = 0.0;
 
     const int64_t nchunks = (nvec + 63) >> 6;
@@ -152,14 +160,17 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
         // fragment loads (16/NG vector rows at a time so the kernel fits 2 waves per SIMD: the
         // other wave's loads then overlap this wave's MFMA phase) ------------------------------------
         constexpr int UH = (NG == 4) ? 2 : 16 / NG;
-        fvec4 t32[R::NT], c32[NG];
+        fvec4 t32[R::NT], ct32[NG];
+        float c32[NG];
         if constexpr (F32) {
 #pragma unroll
             for (int t = 0; t < R::NT; ++t) t32[t] = fvec4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < NG; ++t) c32[t] = fvec4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NG; ++t) { c32[t] = 0.f; ct32[t] = fvec4{0.f, 0.f, 0.f, 0.f}; }
         }
-#pragma unroll
+        // not unrolled: one group's fragment loads in flight at a time keeps the register
+        // footprint at 2-3 waves per SIMD (unrolled, the scheduler hoists every group's loads)
+#pragma unroll 1
         for (int u0 = 0; u0 < 16; u0 += UH) {
             V xf[UH][NG];
 #pragma unroll
@@ -193,7 +204,8 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
                             for (int gj = gi; gj < NG; ++gj)
                                 t32[R::tile(gi, gj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                     aw[gi], a[gj], t32[R::tile(gi, gj)], 0, 0, 0);
-                            c32[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[gi], rb, c32[gi], 0, 0, 0);
+                            if constexpr (CV) c32[gi] = fmaf(aw[gi], rb, c32[gi]);
+                            else ct32[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[gi], rb, ct32[gi], 0, 0, 0);
                         }
                         continue;
                     }
@@ -211,7 +223,8 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
                         for (int gj = gi; gj < NG; ++gj)
                             tile[R::tile(gi, gj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(
                                 aw[gi], a[gj], tile[R::tile(gi, gj)], 0, 0, 0);
-                        ctile[gi] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[gi], rb, ctile[gi], 0, 0, 0);
+                        if constexpr (CV) cacc[gi] = fma(aw[gi], rb, cacc[gi]);
+                        else ctile[gi] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[gi], rb, ctile[gi], 0, 0, 0);
                     }
                 }
             }
@@ -222,9 +235,11 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) tile[t][q4] += (double)t32[t][q4];
 #pragma unroll
-            for (int t = 0; t < NG; ++t)
+            for (int t = 0; t < NG; ++t) {
+                cacc[t] += (double)c32[t];
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) ctile[t][q4] += (double)c32[t][q4];
+                for (int q4 = 0; q4 < 4; ++q4) ctile[t][q4] += (double)ct32[t][q4];
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -246,18 +261,35 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_gramstep(
         }
         __syncthreads();
     }
-    if (c == 0) {
+    // c: lane (c, g) holds the partial of column 16 t + c over its row group (vector form), or
+    // column j = 0 of the c tile holds c (matrix form: rows spread over g and the 4 registers;
+    // staged as 4 slots per column so both forms share the sum below); q: one per wave
 #pragma unroll
-        for (int t = 0; t < NG; ++t)
+    for (int t = 0; t < NG; ++t) {
+        if constexpr (CV) {
+            s_red[wave][(16 * t + c) * 4 + g] = cacc[t];
+        } else {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) s_red[wave][16 * t + (F32 ? 4 * g + q4 : g + 4 * q4)] = ctile[t][q4];
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int row = F32 ? 4 * g + q4 : g + 4 * q4;
+                // D[row][col c] == c_row for every c: lane column c < 4 fills slot c of its rows
+                if (c < 4) s_red[wave][(16 * t + row) * 4 + c] = (c == 0) ? ctile[t][q4] : 0.0;
+            }
+        }
     }
-    if (lane == 0) s_red[wave][B] = qacc;
+    if (lane == 0) s_q[wave] = qacc;
     __syncthreads();
     for (int v = threadIdx.x; v < B + 1; v += blockDim.x) {
         double sum = 0.0;
+        if (v < B) {
 #pragma unroll
-        for (int wv = 0; wv < kGramWaves; ++wv) sum += s_red[wv][v];
+            for (int wv = 0; wv < kGramWaves; ++wv)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) sum += s_red[wv][v * 4 + gg];
+        } else {
+#pragma unroll
+            for (int wv = 0; wv < kGramWaves; ++wv) sum += s_q[wv];
+        }
         partials[(int64_t)(R::OFF_C + v) * gridDim.x + blockIdx.x] = sum;
     }
 }
