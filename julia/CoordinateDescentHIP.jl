@@ -9,6 +9,7 @@
 module CoordinateDescentHIP
 
 using CoordinateDescent, ProximalBase
+using SparseArrays: nnz
 import CoordinateDescent: coordinateDescent!, initialize!, gradient, descendCoordinate!,
                           numCoordinates, CDOptions, CDLeastSquaresLoss, CDSqrtLassoLoss
 
@@ -146,5 +147,14 @@ function coordinateDescent!(x::SparseIterate{T}, f::HipLoss{T}, g::ProxL1, optio
   st.domain_error != 0 && throw(DomainError(NaN, "sqrt-lasso update"))
   pull_iterate!(f, x)
 end
+
+# Optional knobs (no reference counterpart): blocked sweep width, screened full passes, reuse of
+# the carried residual by warm starts (what LassoPath wants: src/lasso.jl:250-252).
+set_sweep_mode!(X::HipMatrix, blocked::Bool, block::Integer=16) =
+  check(X.handle, ccall((:cdh_set_sweep_mode, libcdhip), Int32, (Ptr{Cvoid}, Int32, Int32), X.handle, blocked ? 1 : 0, block))
+set_screening!(X::HipMatrix, on::Bool) =
+  check(X.handle, ccall((:cdh_set_screening, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, on ? 1 : 0))
+set_reuse_residual!(X::HipMatrix, on::Bool) =
+  check(X.handle, ccall((:cdh_set_reuse_residual, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, on ? 1 : 0))
 
 end # module
