@@ -5,7 +5,9 @@
 // because the ORDER of the support is the visit order of an active pass
 // (atom_iterator.jl:18-26).  Coordinates are 0-based here.
 #pragma once
+#include <cstddef>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 namespace cdh {
@@ -15,40 +17,40 @@ public:
     explicit SupportList(int64_t p = 0) { resize(p); }
     void resize(int64_t p) {
         p_ = p; nnz_ = 0;
-        val_.assign((size_t)p, 0.0); slot2ind_.assign((size_t)p, 0); ind2slot_.assign((size_t)p, 0);
+        val_.assign((std::size_t)p, 0.0); slot2ind_.assign((std::size_t)p, 0); ind2slot_.assign((std::size_t)p, 0);
     }
     int64_t size() const { return p_; }
     int64_t nnz() const { return nnz_; }
-    int64_t coord(int64_t slot) const { return slot2ind_[(size_t)slot]; }
-    double slot_value(int64_t slot) const { return val_[(size_t)slot]; }
+    int64_t coord(int64_t slot) const { return slot2ind_[(std::size_t)slot]; }
+    double slot_value(int64_t slot) const { return val_[(std::size_t)slot]; }
     double get(int64_t k) const {
-        const int64_t s = ind2slot_[(size_t)k];
-        return s ? val_[(size_t)(s - 1)] : 0.0;
+        const int64_t s = ind2slot_[(std::size_t)k];
+        return s ? val_[(std::size_t)(s - 1)] : 0.0;
     }
     // setindex!: non-zero to an unstored coordinate appends; zero to a stored one keeps the slot
     void set(int64_t k, double v) {
-        const int64_t s = ind2slot_[(size_t)k];
-        if (s) { val_[(size_t)(s - 1)] = v; return; }
+        const int64_t s = ind2slot_[(std::size_t)k];
+        if (s) { val_[(std::size_t)(s - 1)] = v; return; }
         if (v != 0.0) {
-            val_[(size_t)nnz_] = v; slot2ind_[(size_t)nnz_] = k; ++nnz_;
-            ind2slot_[(size_t)k] = nnz_;
+            val_[(std::size_t)nnz_] = v; slot2ind_[(std::size_t)nnz_] = k; ++nnz_;
+            ind2slot_[(std::size_t)k] = nnz_;
         }
     }
     void clear() {  // fill!(x, 0)
-        for (int64_t i = 0; i < nnz_; ++i) ind2slot_[(size_t)slot2ind_[(size_t)i]] = 0;
+        for (int64_t i = 0; i < nnz_; ++i) ind2slot_[(std::size_t)slot2ind_[(std::size_t)i]] = 0;
         nnz_ = 0;
     }
     // dropzeros! -- resulting order is not pinned by any reference test; swap-with-last
     void dropzeros() {
         int64_t i = 0;
         while (i < nnz_) {
-            if (val_[(size_t)i] == 0.0) {
-                ind2slot_[(size_t)slot2ind_[(size_t)i]] = 0;
+            if (val_[(std::size_t)i] == 0.0) {
+                ind2slot_[(std::size_t)slot2ind_[(std::size_t)i]] = 0;
                 const int64_t last = nnz_ - 1;
                 if (i != last) {
-                    val_[(size_t)i] = val_[(size_t)last];
-                    slot2ind_[(size_t)i] = slot2ind_[(size_t)last];
-                    ind2slot_[(size_t)slot2ind_[(size_t)i]] = i + 1;
+                    val_[(std::size_t)i] = val_[(std::size_t)last];
+                    slot2ind_[(std::size_t)i] = slot2ind_[(std::size_t)last];
+                    ind2slot_[(std::size_t)slot2ind_[(std::size_t)i]] = i + 1;
                 }
                 --nnz_;
             } else {
@@ -69,23 +71,23 @@ private:
 class VisitScheduler {
 public:
     VisitScheduler(int64_t p, bool randomize, uint64_t seed)
-        : p_(p), randomize_(randomize), state_(seed), order_((size_t)p) {
-        for (int64_t i = 0; i < p; ++i) order_[(size_t)i] = i;
+        : p_(p), randomize_(randomize), state_(seed), order_((std::size_t)p) {
+        for (int64_t i = 0; i < p; ++i) order_[(std::size_t)i] = i;
     }
     // reset!(it, fullPass) followed by collect(it): the 0-based visit list of the pass
     void next_pass(const SupportList& x, bool fullPass, std::vector<int64_t>& out) {
         const int64_t L = fullPass ? p_ : x.nnz();
-        out.resize((size_t)L);
+        out.resize((std::size_t)L);
         if (randomize_) {
-            for (int64_t i = 0; i < L; ++i) order_[(size_t)i] = i;
+            for (int64_t i = 0; i < L; ++i) order_[(std::size_t)i] = i;
             for (int64_t i = 0; i + 1 < L; ++i) {
                 const int64_t j = i + (int64_t)(next() % (uint64_t)(L - i));
-                std::swap(order_[(size_t)i], order_[(size_t)j]);
+                std::swap(order_[(std::size_t)i], order_[(std::size_t)j]);
             }
         }
         for (int64_t i = 0; i < L; ++i) {
-            const int64_t o = randomize_ ? order_[(size_t)i] : i;
-            out[(size_t)i] = fullPass ? o : x.coord(o);
+            const int64_t o = randomize_ ? order_[(std::size_t)i] : i;
+            out[(std::size_t)i] = fullPass ? o : x.coord(o);
         }
     }
 
