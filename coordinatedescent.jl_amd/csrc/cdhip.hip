@@ -274,12 +274,20 @@ template <typename T, int B> int32_t launch_block_chunk(cdh_handle h, int m) {
     return CDH_OK;
 }
 
+// blocks of k_gramstep<NG>: as many as stay resident (B = 64 holds 2 waves per SIMD, the narrower
+// ones 3), never more than the partial buffer was sized for
+inline int NGgrid(cdh_handle h, int NG) {
+    const int per_cu = NG == 4 ? std::min(h->gram32_per_cu, 2) : h->gram32_per_cu;
+    return NG >= 2 ? balanced_grid(h->gram_units, (int64_t)h->cus * per_cu) : h->gram_grid;
+}
+
 // wide blocks (B = 16 / 32): MFMA-accumulated Gram kernel + two-stage reduction
 template <typename T, int NG> int32_t launch_gram_chunk(cdh_handle h, int m) {
     using R = GramRec<NG>;
     constexpr int B = R::B;
     // blocks per CU follow the kernel's register footprint (2 waves per SIMD for both widths)
-    const int G = NG >= 2 ? balanced_grid(h->gram_units, (int64_t)h->cus * h->gram32_per_cu) : h->gram_grid;
+    const int G = NGgrid(h, NG);
+    if ((size_t)G * R::N > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partial buffer too small for this grid");
     const T* wts = h->has_w ? (const T*)h->w : (const T*)nullptr;
     int nprev = 0;
     for (int pos0 = 0; pos0 < m; pos0 += B) {
@@ -302,10 +310,6 @@ template <typename T, int NG> int32_t launch_gram_chunk(cdh_handle h, int m) {
     hipLaunchKernelGGL(k_multi_axpy<T>, dim3(h->step_grid), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
                        h->nvec, (T*)h->r, h->d_idx, h->d_hs, last0, m - last0);
     return CDH_OK;
-}
-
-inline int NGgrid(cdh_handle h, int NG) {
-    return NG >= 2 ? balanced_grid(h->gram_units, (int64_t)h->cus * h->gram32_per_cu) : h->gram_grid;
 }
 
 template <typename T> int32_t launch_coord_chunk(cdh_handle h, int m) {
@@ -669,7 +673,9 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->partials_doubles = std::max<size_t>({(size_t)kMaxStepGrid * kNSum,
                                                 (size_t)cus * kBlockGridPerCU * BlockRec<kMaxBlockB>::N,
                                                 (size_t)4096 * kColChunks * 2,
-                                                (size_t)cus * 2 * GramRec<4>::N});
+                                                (size_t)cus * 2 * GramRec<4>::N,
+                                                (size_t)cus * std::max(h->gram32_per_cu, 3) * GramRec<2>::N,
+                                                (size_t)cus * std::max(env_int("CDH_GRAM_GRID_PER_CU", 2), 3) * GramRec<1>::N});
         HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * h->partials_doubles));
         HIPCHK(h, hipMalloc(&h->d_red, sizeof(double) * 4096));
         HIPCHK(h, hipMalloc(&h->d_colout, sizeof(double) * 2 * p));
@@ -991,6 +997,7 @@ static int32_t cdh_gram_impl(cdh_handle h, int64_t m, const int64_t* idx1, doubl
     // one k_gramstep launch with no pending update: r is only read
     const int G = NGgrid(h, 4);
     using R = GramRec<4>;
+    if ((size_t)G * R::N > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partial buffer too small for this grid");
     CHK(dispatch(h, [&](auto* t) {
         using T = std::remove_pointer_t<decltype(t)>;
         hipLaunchKernelGGL((k_gramstep<T, 4, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,

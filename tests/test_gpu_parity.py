@@ -339,10 +339,11 @@ def test_large_problem_properties():
     assert np.max(np.abs(grad[act] - g.lambda0)) < 1e-9       # active set: |X_k'r|/n = lambda
     assert np.all(grad[~act] <= g.lambda0 * (1 + 1e-9))       # inactive: <= lambda
     assert np.max(np.abs(xb[:s] - bstar)) < 0.1
-    f.set_sweep_mode("coord")
-    xc = cd.SparseIterate(p)
-    cd.coordinateDescent_(xc, f, g, cd.CDOptions(maxIter=200, optTol=1e-11, randomize=False))
-    np.testing.assert_allclose(xc.dense(), xb, rtol=0, atol=BETA_TOL)
+    for mode in ("coord", 16, 32, 64):        # every sweep formulation at full-chip grid sizes
+        f.set_sweep_mode("coord") if mode == "coord" else f.set_sweep_mode("block", mode)
+        xc = cd.SparseIterate(p)
+        cd.coordinateDescent_(xc, f, g, cd.CDOptions(maxIter=200, optTol=1e-11, randomize=False))
+        np.testing.assert_allclose(xc.dense(), xb, rtol=0, atol=BETA_TOL)
 
 
 # ---- hipGraph replay of the pass: same launches, same bits ------------------------------------
