@@ -394,8 +394,8 @@ def test_edge_shapes_and_repeated_coordinates(mode):
 # communicator (dlopen of librccl, ncclCommInitRank, ncclAllReduce on the sweep stream between the
 # reduce and the scalar kernels).  RCCL refuses two ranks on one device, so this is as far as a
 # one-GPU box can go; the sharded arithmetic with a real 2-rank all-reduce is the gloo test. ------
-@pytest.mark.parametrize("mode_args", [["--mode", "coord"], ["--block", "8"], ["--block", "32"]],
-                         ids=["coord", "block8", "block32"])
+@pytest.mark.parametrize("mode_args", [["--mode", "coord"], ["--block", "8"], ["--block", "32"], ["--block", "64"]],
+                         ids=["coord", "block8", "block32", "block64"])
 def test_rccl_path_under_torchrun_matches_plain_run(mode_args):
     import json
     import subprocess
