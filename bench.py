@@ -58,14 +58,15 @@ def cpu_baseline(f, n, lam, visits_target_s=12.0):
     """CPU oracle (port of cd_differentiable_function.jl:96-99,107-109) on a 32-column
     slice of the same X, single thread (faithful: the reference has no threading) and
     all host cores (OpenMP over n: a ceiling the reference does not have)."""
-    import ctypes as C
     import numpy as np
+    import coordinatedescent_jl_amd as cd
     import oracle as O
     L = O.lib()
     ncol = 32
-    X = f.X_cols(0, ncol)            # the device-generated data itself
-    y = f.y
+    X = f.X_cols(0, ncol).astype(np.float64, copy=False)   # the device-generated data itself
+    y = f.y.astype(np.float64, copy=False)
     out = {}
+    beta_cpu = None
     for threads in (1, host_threads(int(L.cdo_max_threads()))):
         r = y.copy()
         beta = np.zeros(ncol)
@@ -80,6 +81,18 @@ def cpu_baseline(f, n, lam, visits_target_s=12.0):
         out[threads] = dict(value=visits / dt, unit="coord-updates/s", cores=threads, kind="port",
                             sample=f"{visits} visits cycling a {ncol}-column slice of the same X, n={n}, fp64; "
                                    f"{dt / visits * 1e3:.2f} ms/visit; p-sweep extrapolated x(p/visits)")
+        if threads == 1:
+            beta_cpu, cycles = beta.copy(), (visits + ncol) // ncol
+    # parity at full n on the same slice: the CPU port has cycled the 32
+    # columns to their fixed point; solve the same 32-column problem with the HIP path and compare
+    fg = cd.CDLeastSquaresLoss(y, X)
+    fg.set_sweep_mode("block", 16)
+    xg = cd.SparseIterate(ncol)
+    cd.coordinateDescent_(xg, fg, cd.ProxL1(lam), cd.CDOptions(maxIter=500, optTol=1e-13, randomize=False))
+    out["parity"] = dict(max_abs_beta_diff=float(np.max(np.abs(xg.dense() - beta_cpu))), tolerance=1e-10,
+                         sample=f"n={n}, first {ncol} columns of the same X, lambda as timed; HIP solve "
+                                f"({fg.last_stats['passes']} passes, optTol 1e-13) vs {cycles} cyclic sweeps of the CPU port")
+    fg.close()
     return out
 
 
@@ -202,6 +215,7 @@ def main():
     if cp.rank == 0 and cp.world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(f, n_local, g.lambda0)
         res["cpu_baseline"] = cb[1]
+        res["parity_vs_cpu_port"] = cb.pop("parity")
         mt = [v for k, v in cb.items() if k != 1]
         if mt:
             res["cpu_baseline_all_cores"] = mt[0]
