@@ -46,6 +46,14 @@ template <int NG> struct GramRec {
 
 constexpr int kGramWaves = 4;  // waves per block
 
+// load-group sizes of k_gramstep (-D overrides build tuning experiments)
+#ifndef CDH_PG
+#define CDH_PG(NG) ((NG) == 4 ? 16 : 8)          // previous-block columns loaded per round (B=64: 16 measured 3-4 % faster than 4)
+#endif
+#ifndef CDH_UH
+#define CDH_UH(NG) ((NG) == 4 ? 2 : 16 / (NG))   // fragment-load vector rows in flight per group
+#endif
+
 template <typename T, int NG, bool NT_>
 __global__ __launch_bounds__(64 * kGramWaves, (NG == 4) ? 2 : 3) void k_gramstep(
     const T* __restrict__ X, int64_t ld, int64_t nvec, const T* __restrict__ w, T* __restrict__ r,
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4) ? 2 : 3) void k_gramstep
             double re[NV];
 #pragma unroll
             for (int e = 0; e < NV; ++e) re[e] = (double)rr[e];
-            constexpr int PG = (NG == 4) ? 4 : 8;      // independent loads in flight per group
+            constexpr int PG = CDH_PG(NG);             // independent loads in flight per group
             for (int i0 = 0; i0 < nzp; i0 += PG) {
                 V xp[PG];
 #pragma unroll
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4) ? 2 : 3) void k_gramstep
         // ---- phase B: tiles += X_I' X_J, X_I' r' over the chunk's rows, in UH-sized groups of
         // fragment loads (16/NG vector rows at a time so the kernel fits 2 waves per SIMD: the
         // other wave's loads then overlap this wave's MFMA phase) ------------------------------------
-        constexpr int UH = (NG == 4) ? 2 : 16 / NG;
+        constexpr int UH = CDH_UH(NG);
         fvec4 t32[R::NT], ct32[NG];
         float c32[NG];
         if constexpr (F32) {
