@@ -92,6 +92,7 @@ struct cdh_handle_s {
     size_t partials_doubles = 0;
     Ctrl ctrl{};
     bool has_omega = false, has_w = false, y_set = false;
+    std::vector<double> h_omega;  // host copy of the penalty weights (thresholds, objective)
     cdh::SupportList x;
     int mode = CDH_SWEEP_COORD, blockB = 8;
     bool use_graph = false;
@@ -459,12 +460,7 @@ constexpr int kScreen = 64;
 int32_t screened_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH) {
     const int B = (h->mode == CDH_SWEEP_BLOCK) ? h->blockB : 1;
     const double lam = h->ctrl.lambda0, nt = (double)h->n_total;
-    std::vector<double> om;
-    if (h->has_omega) {
-        om.resize((size_t)h->p);
-        HIPCHK(h, hipMemcpyAsync(om.data(), h->omega, sizeof(double) * h->p, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
+    const std::vector<double>& om = h->h_omega;
     std::vector<double> cd((size_t)(2 * kScreen));
     int64_t pos = 0, cool = 0, cool_len = kScreen;
     while (pos < m) {
@@ -562,11 +558,7 @@ int32_t lambda_max(cdh_handle h, double* out) {
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->loss == CDH_SQRT) denom = std::sqrt(h->h_red[1]);
-    std::vector<double> om;
-    if (h->has_omega) {
-        om.resize((size_t)h->p);
-        HIPCHK(h, hipMemcpy(om.data(), h->omega, sizeof(double) * h->p, hipMemcpyDeviceToHost));
-    }
+    const std::vector<double>& om = h->h_omega;
     double lmax = 0.0;
     for (int64_t k = 0; k < h->p; ++k) {
         double t = std::fabs(-cd[(size_t)(2 * k)] / denom);
@@ -808,6 +800,7 @@ static int32_t cdh_set_penalty_impl(cdh_handle h, double lambda0, const double* 
     if (omega) {
         if (n_omega != h->p) return fail(h, CDH_DIM_MISMATCH, "length(g.lambda) != numCoordinates(f)");
         HIPCHK(h, hipMemcpyAsync(h->omega, omega, sizeof(double) * h->p, hipMemcpyHostToDevice, h->stream));
+        h->h_omega.assign(omega, omega + h->p);
         h->has_omega = true;
     } else {
         h->has_omega = false;
@@ -1038,11 +1031,7 @@ static int32_t cdh_objective_impl(cdh_handle h, double* out) {
     HIPCHK(h, hipSetDevice(h->device));
     CHK(resid_moments_dev(h));
     HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
-    std::vector<double> om;
-    if (h->has_omega) {
-        om.resize((size_t)h->p);
-        HIPCHK(h, hipMemcpyAsync(om.data(), h->omega, sizeof(double) * h->p, hipMemcpyDeviceToHost, h->stream));
-    }
+    const std::vector<double>& om = h->h_omega;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     double pen = 0.0;
     for (int64_t s = 0; s < h->x.nnz(); ++s)
