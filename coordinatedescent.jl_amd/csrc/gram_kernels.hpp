@@ -54,8 +54,13 @@ constexpr int kGramWaves = 4;  // waves per block
 #define CDH_UH(NG) ((NG) == 4 ? 2 : 16 / (NG))   // fragment-load vector rows in flight per group
 #endif
 
-template <typename T, int NG, bool NT_>
-__global__ __launch_bounds__(64 * kGramWaves, (NG == 4) ? 2 : 3) void k_gramstep(
+// LT (B = 16 only): operand columns are loaded fully coalesced (one column per instruction, 64
+// consecutive vectors = 1 KB) and transposed into the MFMA fragment layout through a wave-private
+// LDS tile, instead of fragment-shaped loads that take 64 B from each of 16 columns.
+constexpr int kXS = 66;   // LDS column stride in 16-B slots: 64 + 2 pad (ds_read_b128 conflict-free)
+
+template <typename T, int NG, bool NT_, bool LT = false>
+__global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gramstep(
     const T* __restrict__ X, int64_t ld, int64_t nvec, const T* __restrict__ w, T* __restrict__ r,
     const int64_t* __restrict__ idx, const double* __restrict__ hs, int pos0, int nb, int nprev,
     double* __restrict__ partials) {
@@ -67,8 +72,13 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4) ? 2 : 3) void k_gramstep
     __shared__ V s_r[kGramWaves][64];            // r' of the wave's current 64-vector chunk
     __shared__ double s_hp[B];
     __shared__ int64_t s_kp[B];
-    __shared__ double s_red[kGramWaves][256];    // end-of-kernel cross-wave reduction, per tile
     __shared__ double s_q[kGramWaves];
+    static_assert(!LT || NG == 1, "the LDS-transposed operand path is for B = 16");
+    __shared__ V s_x[LT ? kGramWaves : 1][LT ? 16 * kXS : 1];
+    // end-of-kernel cross-wave reduction, per tile; with LT it reuses the (then idle) operand
+    // tiles so the block stays under 80 KB of LDS = 2 blocks per CU
+    __shared__ double s_red_own[LT ? 1 : kGramWaves][LT ? 1 : 256];
+    double (*s_red)[256] = LT ? reinterpret_cast<double (*)[256]>(&s_x[0][0]) : reinterpret_cast<double (*)[256]>(&s_red_own[0][0]);
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
 
@@ -181,12 +191,27 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4) ? 2 : 3) void k_gramstep
 #pragma unroll 1
         for (int u0 = 0; u0 < 16; u0 += UH) {
             V xf[UH][NG];
+            if constexpr (LT) {
+                V xc[16];
 #pragma unroll
-            for (int u = 0; u < UH; ++u) {
-                const int64_t v = v0 + 4 * (u0 + u) + g;
+                for (int j = 0; j < 16; ++j) {   // column j of the block: wave-uniform pointer
+                    const V* colp = reinterpret_cast<const V*>(X + idx[pos0 + (j < nb ? j : 0)] * ld);
+                    xc[j] = (j < nb && inb) ? ld_stream<NT_>(colp + jv) : vzero((V*)nullptr);
+                }
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int grp = 0; grp < NG; ++grp)
-                    xf[u][grp] = (act[grp] && v < nvec) ? ld_stream<NT_>(cv[grp] + v) : vzero((V*)nullptr);
+                for (int j = 0; j < 16; ++j) s_x[wave][j * kXS + lane] = xc[j];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < UH; ++u) xf[u][0] = s_x[wave][c * kXS + 4 * (u0 + u) + g];
+            } else {
+#pragma unroll
+                for (int u = 0; u < UH; ++u) {
+                    const int64_t v = v0 + 4 * (u0 + u) + g;
+#pragma unroll
+                    for (int grp = 0; grp < NG; ++grp)
+                        xf[u][grp] = (act[grp] && v < nvec) ? ld_stream<NT_>(cv[grp] + v) : vzero((V*)nullptr);
+                }
             }
 #pragma unroll
             for (int u = 0; u < UH; ++u) {
@@ -252,6 +277,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4) ? 2 : 3) void k_gramstep
         __builtin_amdgcn_wave_barrier();
     }
 
+    if constexpr (LT) __syncthreads();   // every wave is done with its operand tile before s_red aliases it
     // ---- per-wave record -> LDS -> sum over the block's waves -> value-major partials, one tile
     // at a time (an 8 KB staging buffer instead of the whole record x 4 waves) --------------------
     qacc = wave_sum(qacc);
