@@ -106,7 +106,7 @@ struct cdh_handle_s {
     int step_grid = 1, block_grid = 1, gram_grid = 1, cus = 1, gram32_per_cu = 1;
     int64_t gram_units = 1;
     bool nt = true;  // non-temporal loads for the X column streams
-    bool lt = true;  // B = 16: coalesced operand loads transposed through LDS (measured ~5 % faster)
+    int lt = 2;      // coalesced operand loads transposed through LDS: 0 off, 1 on, 2 by size (default)
     // comm
     void* comm = nullptr;
     int rank = 0, nranks = 1;
@@ -294,11 +294,14 @@ template <typename T, int NG> int32_t launch_gram_chunk(cdh_handle h, int m) {
     int nprev = 0;
     for (int pos0 = 0; pos0 < m; pos0 += B) {
         const int nb = std::min(B, m - pos0);
-        if (NG == 1 && h->lt) {
-            if constexpr (NG == 1)
-                hipLaunchKernelGGL((k_gramstep<T, 1, true, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
-                                   (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb,
-                                   nprev, h->d_partials);
+        // LDS-transposed (fully coalesced) operand loads: measured -5 % at >= 5e6 rows for every
+        // width; at 1.25e6 rows neutral for B = 64 and +5 % for B = 32, so the narrower widths take
+        // it only on long columns.  fp32 B = 64 would spill: fragment path.
+        const bool use_lt = h->lt == 1 || (h->lt == 2 && (NG == 4 || h->n >= 2000000));
+        if (use_lt && !(NG == 4 && sizeof(T) == 4)) {
+            hipLaunchKernelGGL((k_gramstep<T, NG, true, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
+                               (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb,
+                               nprev, h->d_partials);
         } else if (h->nt)
             hipLaunchKernelGGL((k_gramstep<T, NG, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
                                (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
@@ -639,7 +642,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         // tuning knobs (experiments only; defaults are the measured best)
         auto env_int = [](const char* nm, int dflt) { const char* v = getenv(nm); return v ? atoi(v) : dflt; };
         h->nt = env_int("CDH_NT", 1) != 0;
-        h->lt = env_int("CDH_LT", 1) != 0;
+        h->lt = env_int("CDH_LT", 2);
         const int step_per_cu = std::max(1, env_int("CDH_STEP_GRID_PER_CU", 8));
         const int block_per_cu = std::max(1, std::min(kBlockGridPerCU, env_int("CDH_BLOCK_GRID_PER_CU", 3)));
         const int64_t want = (h->nvec + (int64_t)kBlock * kUnroll - 1) / ((int64_t)kBlock * kUnroll);

@@ -54,10 +54,18 @@ constexpr int kGramWaves = 4;  // waves per block
 #define CDH_UH(NG) ((NG) == 4 ? 2 : 16 / (NG))   // fragment-load vector rows in flight per group
 #endif
 
-// LT (B = 16 only): operand columns are loaded fully coalesced (one column per instruction, 64
-// consecutive vectors = 1 KB) and transposed into the MFMA fragment layout through a wave-private
-// LDS tile, instead of fragment-shaped loads that take 64 B from each of 16 columns.
-constexpr int kXS = 66;   // LDS column stride in 16-B slots: 64 + 2 pad (ds_read_b128 conflict-free)
+// LT: operand columns are loaded fully coalesced and transposed into the MFMA fragment layout
+// through a wave-private LDS tile, instead of fragment-shaped loads that take 64 B from each of 16
+// columns.  The tile holds all 16*NG columns of the block for a sub-chunk of 64/NG vectors; one load
+// instruction covers NG columns x 64/NG consecutive vectors (1 KB, 512 B or 256 B runs: whole
+// lines), and the wave's 64-vector chunk is consumed in NG sub-chunks.  Column stride = run + pad
+// slots of 16 B; pad 2 makes the ds_read_b128 fragment reads conflict-free, B = 64 takes pad 1 (one
+// 2-way pair) to keep a block under 80 KB of LDS = 2 blocks per CU.
+template <int NG> struct LtTile {
+    static constexpr int SV = 64 / NG;                    // vectors per sub-chunk
+    static constexpr int XS = SV + (NG == 4 ? 1 : 2);     // column stride in 16-B slots
+    static constexpr int SLOTS = 16 * NG * XS;
+};
 
 template <typename T, int NG, bool NT_, bool LT = false>
 __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gramstep(
@@ -73,8 +81,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
     __shared__ double s_hp[B];
     __shared__ int64_t s_kp[B];
     __shared__ double s_q[kGramWaves];
-    static_assert(!LT || NG == 1, "the LDS-transposed operand path is for B = 16");
-    __shared__ V s_x[LT ? kGramWaves : 1][LT ? 16 * kXS : 1];
+    __shared__ V s_x[LT ? kGramWaves : 1][LT ? LtTile<NG>::SLOTS : 1];
     // end-of-kernel cross-wave reduction, per tile; with LT it reuses the (then idle) operand
     // tiles so the block stays under 80 KB of LDS = 2 blocks per CU
     __shared__ double s_red_own[LT ? 1 : kGramWaves][LT ? 1 : 256];
@@ -112,6 +119,19 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
         cv[grp] = reinterpret_cast<const V*>(X + idx[pos0 + (act[grp] ? i : 0)] * ld);
     }
     V* __restrict__ rv = reinterpret_cast<V*>(r);
+    // LT: load instruction t of a sub-chunk covers columns t*NG .. t*NG+NG-1; this lane takes
+    // column t*NG + lt_cl at vector lt_vl of the sub-chunk
+    const int lt_cl = lane / LtTile<NG>::SV, lt_vl = lane % LtTile<NG>::SV;
+    const V* lt_col[LT ? 16 : 1];
+    unsigned lt_act = 0;
+    if constexpr (LT) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int col = t * NG + lt_cl;
+            if (col < nb) lt_act |= 1u << t;
+            lt_col[t] = reinterpret_cast<const V*>(X + idx[pos0 + (col < nb ? col : 0)] * ld);
+        }
+    }
 
     // fp32 storage: each chunk (256 rows) is accumulated by v_mfma_f32_16x16x4_f32 from zero and
     // folded into the fp64 running tiles at the end of the chunk -- half the matrix-pipe time of
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
             double re[NV];
 #pragma unroll
             for (int e = 0; e < NV; ++e) re[e] = (double)rr[e];
-            constexpr int PG = CDH_PG(NG);             // independent loads in flight per group
+            constexpr int PG = (LT && NG == 4) ? 8 : CDH_PG(NG);   // independent loads in flight per group
             for (int i0 = 0; i0 < nzp; i0 += PG) {
                 V xp[PG];
 #pragma unroll
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
         // ---- phase B: tiles += X_I' X_J, X_I' r' over the chunk's rows, in UH-sized groups of
         // fragment loads (16/NG vector rows at a time so the kernel fits 2 waves per SIMD: the
         // other wave's loads then overlap this wave's MFMA phase) ------------------------------------
-        constexpr int UH = CDH_UH(NG);
+        constexpr int UH = LT ? 16 / NG : CDH_UH(NG);
         fvec4 t32[R::NT], ct32[NG];
         float c32[NG];
         if constexpr (F32) {
@@ -192,18 +212,22 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
         for (int u0 = 0; u0 < 16; u0 += UH) {
             V xf[UH][NG];
             if constexpr (LT) {
+                constexpr int SV = LtTile<NG>::SV, XS = LtTile<NG>::XS;
                 V xc[16];
+                const int64_t vsub = v0 + 4 * u0 + lt_vl;       // this lane's vector in the sub-chunk
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {   // column j of the block: wave-uniform pointer
-                    const V* colp = reinterpret_cast<const V*>(X + idx[pos0 + (j < nb ? j : 0)] * ld);
-                    xc[j] = (j < nb && inb) ? ld_stream<NT_>(colp + jv) : vzero((V*)nullptr);
-                }
+                for (int t = 0; t < 16; ++t)
+                    xc[t] = (((lt_act >> t) & 1) && vsub < nvec) ? ld_stream<NT_>(lt_col[t] + vsub)
+                                                                 : vzero((V*)nullptr);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int j = 0; j < 16; ++j) s_x[wave][j * kXS + lane] = xc[j];
+                for (int t = 0; t < 16; ++t) s_x[wave][(t * NG + lt_cl) * XS + lt_vl] = xc[t];
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int u = 0; u < UH; ++u) xf[u][0] = s_x[wave][c * kXS + 4 * (u0 + u) + g];
+                for (int u = 0; u < UH; ++u)
+#pragma unroll
+                    for (int grp = 0; grp < NG; ++grp) xf[u][grp] = s_x[wave][(16 * grp + c) * XS + 4 * u + g];
+                (void)SV;
             } else {
 #pragma unroll
                 for (int u = 0; u < UH; ++u) {
