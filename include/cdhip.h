@@ -62,7 +62,9 @@ typedef enum cdh_loss { CDH_LS = 0, CDH_SQRT = 1, CDH_WLS = 2 } cdh_loss;
  *                    columns once and returns X_B'r and the B x B Gram block, the
  *                    B scalar updates run on those numbers (algebraically the
  *                    same iterates), then one rank-B residual update.  One
- *                    all-reduce per block.  LS and SQRT losses only. */
+ *                    all-reduce per block.  B in {2, 4, 8, 16, 32, 64}; with
+ *                    observation weights (CDH_WLS) B >= 16, narrower widths then
+ *                    run the per-coordinate sweep. */
 typedef enum cdh_sweep_mode { CDH_SWEEP_COORD = 0, CDH_SWEEP_BLOCK = 1 } cdh_sweep_mode;
 
 /* CDOptions (utils.jl:7-20), field for field, + the seed of the substitute RNG
