@@ -589,3 +589,23 @@ def test_correlated_design(mode, rho):
     # slow convergence amplifies rounding: 1e-9 on beta here, objective to 1e-12
     np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-9)
     np.testing.assert_allclose(cd.objective(f), O.objective(fo, O.ProxL1(0.01), xo), rtol=1e-12)
+
+
+# ---- analytic known answer, independent of the oracle: orthogonal design ------------------------
+@pytest.mark.parametrize("mode", MODES, ids=lambda m: f"{m[0]}{m[1]}")
+def test_orthogonal_design_closed_form(mode):
+    rng = np.random.default_rng(21)
+    n, p = 256, 40
+    Q, _ = np.linalg.qr(rng.standard_normal((n, p)))
+    X = np.asfortranarray(Q * np.sqrt(n))
+    Y = X[:, :5] @ np.array([3.0, -2.0, 1.0, 0.5, -0.2]) + 0.3 * rng.standard_normal(n)
+    om = rng.random(p) + 0.5
+    lam = 0.25
+    z = X.T @ Y / n
+    want = np.sign(z) * np.maximum(np.abs(z) - lam * om, 0.0)   # beta_j = S(X_j'y/n, lambda w_j)
+    f = cd.CDLeastSquaresLoss(Y, X)
+    _set_mode(f, mode)
+    x = cd.SparseIterate(p)
+    cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(optTol=1e-13, randomize=True, seed=2))
+    np.testing.assert_allclose(x.dense(), want, rtol=0, atol=1e-12)
+    assert f.last_stats["passes"] == 3 and f.last_stats["full_passes"] == 2   # full, active, full

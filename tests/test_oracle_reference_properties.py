@@ -284,3 +284,25 @@ def test_weighted_ls_matches_row_scaled_ls():
     O.coordinateDescent_(xs, O.CDLeastSquaresLoss(Y * sw, np.asfortranarray(X * sw[:, None])),
                          O.ProxL1(0.05), O.CDOptions(optTol=1e-12, randomize=False))
     np.testing.assert_allclose(xw.dense(), xs.dense(), rtol=0, atol=1e-10)
+
+
+def test_orthogonal_design_closed_form():
+    """Independent analytic check (not from the reference's tests): with X'X = n I the Lasso
+    solution is beta_j = S(X_j'y / n, lambda * omega_j) in one pass, whatever the visit order."""
+    rng = np.random.default_rng(21)
+    n, p = 256, 40
+    Q, _ = np.linalg.qr(rng.standard_normal((n, p)))
+    X = np.asfortranarray(Q * np.sqrt(n))
+    Y = X[:, :5] @ np.array([3.0, -2.0, 1.0, 0.5, -0.2]) + 0.3 * rng.standard_normal(n)
+    om = rng.random(p) + 0.5
+    lam = 0.25
+    z = X.T @ Y / n
+    want = np.sign(z) * np.maximum(np.abs(z) - lam * om, 0.0)
+    for rand in (False, True):
+        x = O.SparseIterate(p)
+        st = O.coordinateDescent_(x, O.CDLeastSquaresLoss(Y, X), O.ProxL1(lam, om),
+                                  O.CDOptions(optTol=1e-13, randomize=rand, seed=2))
+        np.testing.assert_allclose(x.dense(), want, rtol=0, atol=1e-13)
+        # the state machine of coordinate_descent.jl:65-92: full pass (moves), active pass
+        # (nothing moves -> converged), full pass (still converged -> stop)
+        assert st["passes"] == 3 and st["full_passes"] == 2
