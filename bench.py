@@ -114,6 +114,11 @@ def main():
     ap.add_argument("--lam-frac", type=float, default=1e-6, help="lambda / lambda_max")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the secondary sparse-regime timing")
+    ap.add_argument("--exchange", default=os.environ.get("CDH_EXCHANGE", "rccl"), choices=["rccl", "p2p"],
+                    help="exchange of the timed region when sharded (p2p: opt-in direct exchange, falls back "
+                         "to rccl if its self-test fails)")
+    ap.add_argument("--no-exchange-trial", action="store_true",
+                    help="sharded runs: skip the untimed trial of the other exchange after the timed region")
     a = ap.parse_args()
 
     import numpy as np
@@ -133,6 +138,9 @@ def main():
     f, bstar = cd.CDLeastSquaresLoss.generate(n_local, a.cols, seed=123, s=a.planted, noise=a.noise, dtype=dtype,
                                               device=device, n_total=a.rows, row_offset=row0)
     sharded.connect(f, cp)
+    exchange = "rccl"
+    if cp.world > 1 and a.exchange == "p2p" and sharded.connect_p2p(f, cp):
+        exchange = "p2p"
     if a.block is None:
         a.block = 16 if cp.world == 1 else 64
     f.set_sweep_mode(a.mode, a.block)
@@ -164,6 +172,7 @@ def main():
     cp.barrier()
     dt = cp.max_over_ranks(time.perf_counter() - t0)
     ev_ms, launches, alg_bytes = f.profile_end()
+    beta_timed, moved = x.dense().copy(), int(x.nnz)
 
     # secondary, outside the timed region: the "sparse" regime of SURVEY 8d (lambda = 0.5 lambda_max,
     # few coordinates move, a visit is dots only).  Reported for context; never part of `value`.
@@ -185,6 +194,41 @@ def main():
         sparse = {"lambda_over_lambda_max": 0.5, "ms_per_sweep": dts / nsp * 1e3,
                   "coord_updates_per_sec": nsp * a.cols / dts, "nnz": int(x.nnz)}
 
+    # sharded runs, outside the timed region: a guarded trial of the opt-in direct exchange (never part
+    # of `value`).  Local failures are caught; the only control-plane collectives are the ones every
+    # rank reaches (connect_p2p's and the two reductions below).
+    trial = None
+    if cp.world > 1 and exchange == "rccl" and not a.no_exchange_trial:
+        trial, t_loc, ok_loc, err_loc = {"exchange": "p2p"}, 0.0, False, 0.0
+        try:
+            connected = sharded.connect_p2p(f, cp)
+        except Exception as e:          # pragma: no cover - connect_p2p is written not to raise
+            connected, trial["error"] = False, str(e)[:200]
+        trial["selftest"] = bool(connected)
+        if connected:
+            try:
+                step()
+                L.cdh_synchronize(f._h)
+                tt = time.perf_counter()
+                for _ in range(a.steps):
+                    step()
+                L.cdh_synchronize(f._h)
+                t_loc = time.perf_counter() - tt
+                err_loc = float(np.max(np.abs(x.dense() - beta_timed)))
+                ok_loc = True
+            except Exception as e:
+                trial["error"] = str(e)[:200]
+            try:
+                f.p2p_enable(False)
+            except Exception:
+                pass
+        all_ok = cp.sum_over_ranks(1.0 if ok_loc else 0.0) == cp.world
+        t_max = cp.max_over_ranks(t_loc)
+        if connected:
+            trial.update({"completed_on_all_ranks": bool(all_ok),
+                          "ms_per_step": t_max / a.steps * 1e3 if all_ok else None,
+                          "max_abs_dbeta_vs_rccl": err_loc if ok_loc else None})
+
     updates = a.steps * a.cols
     value = updates / dt
     esz = np.dtype(dtype).itemsize
@@ -200,7 +244,8 @@ def main():
         "config": {"workload": f"lasso_full_cyclic_sweep_gaussian_n{a.rows}_p{a.cols}_{a.dtype}_allmove",
                    "n": a.rows, "p": a.cols, "s": a.planted, "noise": a.noise, "lambda_over_lambda_max": a.lam_frac,
                    "sweep_mode": a.mode + (str(a.block) if a.mode == "block" else ""),
-                   "parallelism": f"rows{cp.world}", "moved_per_sweep": int(x.nnz), "last_maxH": maxh},
+                   "parallelism": f"rows{cp.world}", "exchange": exchange if cp.world > 1 else None,
+                   "moved_per_sweep": moved, "last_maxH": maxh},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": profiled_traffic(kernel, n_local, a.cols, a.dtype, a.block if a.mode == "block" else 1),
@@ -212,6 +257,8 @@ def main():
     }
     if sparse is not None:
         res["sparse_regime"] = sparse
+    if trial is not None:
+        res["exchange_trial"] = trial
     if cp.rank == 0 and cp.world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(f, n_local, g.lambda0)
         res["cpu_baseline"] = cb[1]

@@ -126,6 +126,10 @@ def lib():
         "cdh_set_screening": [vp, i32],
         "cdh_comm_unique_id": [vp],
         "cdh_comm_init": [vp, vp, i32, i32],
+        "cdh_p2p_local_handle": [vp, vp],
+        "cdh_p2p_connect": [vp, vp, i32, i32],
+        "cdh_p2p_enable": [vp, i32],
+        "cdh_exchange_probe": [vp, vp, i64],
         "cdh_profile_begin": [vp],
         "cdh_profile_end": [vp, P(f64), P(i64), P(f64)],
     }

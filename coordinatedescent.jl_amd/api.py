@@ -293,6 +293,26 @@ class _HipLoss(CoordinateDifferentiableFunction):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         check(self._L.cdh_comm_init(self._h, buf, int(rank), int(nranks)), self._h)
 
+    def p2p_local_handle(self) -> bytes:
+        buf = C.create_string_buffer(64)
+        check(self._L.cdh_p2p_local_handle(self._h, buf), self._h)
+        return buf.raw
+
+    def p2p_connect(self, handles: bytes, rank: int, nranks: int):
+        if len(handles) != 64 * int(nranks):
+            raise ArgumentError("p2p_connect needs 64 bytes per rank")
+        buf = C.create_string_buffer(bytes(handles), len(handles))
+        check(self._L.cdh_p2p_connect(self._h, buf, int(rank), int(nranks)), self._h)
+
+    def p2p_enable(self, on=True):
+        check(self._L.cdh_p2p_enable(self._h, int(bool(on))), self._h)
+
+    def exchange_probe(self, values):
+        """All-reduce (sum) up to 4096 doubles through the active exchange; returns the sums."""
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        check(self._L.cdh_exchange_probe(self._h, v.ctypes.data_as(C.c_void_p), v.size), self._h)
+        return v
+
     def profile_begin(self):
         check(self._L.cdh_profile_begin(self._h), self._h)
 

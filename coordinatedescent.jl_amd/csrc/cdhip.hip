@@ -16,6 +16,7 @@
 
 #include "kernels.hpp"
 #include "gram_kernels.hpp"
+#include "p2p_exchange.hpp"
 #include "sparse_iterate.hpp"
 
 using namespace cdk;
@@ -110,6 +111,14 @@ struct cdh_handle_s {
     // comm
     void* comm = nullptr;
     int rank = 0, nranks = 1;
+    // optional direct exchange of the short records (p2p_exchange.hpp); off unless connected and enabled
+    unsigned long long* p2p_inbox = nullptr;
+    cdk::P2PPeers p2p_peers{};
+    std::vector<void*> p2p_mapped;
+    int* p2p_timeout = nullptr;  // pinned host flag written by a kernel whose bounded spin ran out
+    unsigned p2p_epoch = 0, p2p_spin_limit = cdk::kP2PSpinLimit;
+    int p2p_ranks = 0;
+    bool p2p_on = false, p2p_dead = false;
     // profile
     bool prof = false;
     double prof_ms = 0.0, prof_bytes = 0.0;
@@ -163,8 +172,35 @@ int32_t upload_ctrl(cdh_handle h) {
     return CDH_OK;
 }
 
+inline bool sharded(const cdh_handle_s* h) { return h->comm != nullptr || h->p2p_on; }
+
+int32_t p2p_check(cdh_handle h) {
+    // reported once, by the call that hit it; the handle then continues without the direct exchange
+    if (h->p2p_on && *(volatile int*)h->p2p_timeout) {
+        h->p2p_on = false;
+        h->p2p_dead = true;
+        h->err = "p2p exchange timed out waiting for a peer (rank died, or ranks ran different sweeps)";
+        return CDH_RCCL_ERROR;
+    }
+    return CDH_OK;
+}
+
 int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
-    if (!h->comm) return CDH_OK;
+    if (h->p2p_on && (count <= (size_t)cdk::kP2PMaxCount || !h->comm)) {
+        CHK(p2p_check(h));
+        for (size_t o = 0; o < count; o += cdk::kP2PMaxCount) {
+            const int c = (int)std::min<size_t>(cdk::kP2PMaxCount, count - o);
+            h->p2p_epoch = h->p2p_epoch == 0xffffffffu ? 2u : h->p2p_epoch + 1u;  // 0 = never written
+            hipLaunchKernelGGL(cdk::k_p2p_allreduce, dim3((c + 255) / 256), dim3(256), 0, h->stream, dbuf + o, c,
+                               h->p2p_peers, h->rank, h->p2p_ranks, h->p2p_epoch, h->p2p_spin_limit, h->p2p_timeout);
+        }
+        HIPCHK(h, hipGetLastError());
+        return CDH_OK;
+    }
+    if (!h->comm) {
+        if (h->p2p_dead) return fail(h, CDH_RCCL_ERROR, "the shard lost its only exchange (p2p timed out, no communicator)");
+        return CDH_OK;
+    }
     int rc = g_rccl.AllReduce(dbuf, dbuf, count, kNcclDouble, kNcclSum, h->comm, h->stream);
     if (rc != 0) {
         h->err = std::string("ncclAllReduce failed: ") +
@@ -255,7 +291,7 @@ template <typename T, int B> int32_t launch_block_chunk(cdh_handle h, int m) {
         else
             hipLaunchKernelGGL((k_blockstep<T, B, false>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X,
                                h->ld, h->nvec, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev, h->d_partials);
-        if (!h->comm) {
+        if (!sharded(h)) {
             hipLaunchKernelGGL((k_block_finalize<B, true>), dim3(1), dim3(1024), 0, h->stream,
                                h->d_partials, G, nb, h->d_ctrl, h->beta, h->omega, h->d_idx, h->d_hs,
                                h->d_newval, h->d_touched, pos0, h->d_red);
@@ -334,7 +370,7 @@ template <typename T> int32_t launch_coord_chunk(cdh_handle h, int m) {
         else
             hipLaunchKernelGGL((k_step<T, false, false>), dim3(G), dim3(kBlock), 0, h->stream, (const T*)h->X,
                                h->ld, h->nvec, (const T*)nullptr, (T*)h->r, h->d_idx, h->d_hs, pos, h->d_partials);
-        if (!h->comm) {
+        if (!sharded(h)) {
             hipLaunchKernelGGL(k_finalize<true>, dim3(1), dim3(kBlock), 0, h->stream, h->d_partials, G,
                                h->d_ctrl, h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched,
                                pos, h->d_red);
@@ -386,7 +422,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     // every kernel takes its visit position as a literal and reads idx / hs / lambda from device
     // memory -- so one captured graph serves every later pass of that length.  (Not used with a
     // communicator: RCCL calls are left out of stream capture.)
-    if (h->use_graph && !h->comm) {
+    if (h->use_graph && !sharded(h)) {
         const uint64_t key = ((uint64_t)m << 16) | ((uint64_t)(blocked ? h->blockB : 0) << 4) |
                              (h->chunk_dup ? 4u : 0u) | (h->has_w ? 2u : 0u) | (h->nt ? 1u : 0u);
         hipGraphExec_t exec = nullptr;
@@ -416,6 +452,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     HIPCHK(h, hipMemcpyAsync(h->h_touched, h->d_touched, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    CHK(p2p_check(h));
     if (h->h_ctrl->domain_error) h->domain_error = true;
     const double mh = h->h_ctrl->maxH;
     if (mh > *maxH || mh != mh) *maxH = mh;
@@ -582,6 +619,9 @@ void free_all(cdh_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    for (void* m : h->p2p_mapped) (void)hipIpcCloseMemHandle(m);
+    if (h->p2p_inbox) (void)hipFree(h->p2p_inbox);
+    if (h->p2p_timeout) (void)hipHostFree(h->p2p_timeout);
     for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
     void* dev[] = {h->X, h->y, h->r, h->w, h->beta, h->omega, h->d_ctrl, h->d_idx, h->d_hs, h->d_newval,
                    h->d_touched, h->d_partials, h->d_red, h->d_colout, h->d_sup_idx, h->d_sup_val};
@@ -1091,6 +1131,70 @@ int32_t cdh_comm_init(cdh_handle h, const void* id_128_bytes, int32_t rank, int3
     }
     h->rank = rank; h->nranks = nranks;
     return CDH_OK;
+}
+
+// ---- optional direct exchange (p2p_exchange.hpp) -------------------------------------------------
+int32_t cdh_p2p_local_handle(cdh_handle h, void* out_64_bytes) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size is part of the ABI");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->p2p_inbox) {
+        // polled by this GPU while peers write it: must not be served from a stale L2 line
+        void* q = nullptr;
+        if (hipExtMallocWithFlags(&q, kP2PInboxBytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(h, hipExtMallocWithFlags(&q, kP2PInboxBytes, hipDeviceMallocFinegrained));
+        }
+        h->p2p_inbox = (unsigned long long*)q;
+        HIPCHK(h, hipMemset(h->p2p_inbox, 0, kP2PInboxBytes));  // tag 0 = never written; epochs start at 1
+        HIPCHK(h, hipHostMalloc((void**)&h->p2p_timeout, sizeof(int), hipHostMallocDefault));
+        *h->p2p_timeout = 0;
+        HIPCHK(h, hipDeviceSynchronize());
+    }
+    hipIpcMemHandle_t ipc;
+    HIPCHK(h, hipIpcGetMemHandle(&ipc, h->p2p_inbox));
+    std::memcpy(out_64_bytes, &ipc, sizeof ipc);
+    return CDH_OK;
+}
+
+int32_t cdh_p2p_connect(cdh_handle h, const void* handles_64_bytes_each, int32_t rank, int32_t nranks) {
+    if (nranks < 1 || nranks > kP2PMaxRanks || rank < 0 || rank >= nranks)
+        return fail(h, CDH_BAD_ARG, "p2p exchange: bad rank / nranks (at most 8 ranks)");
+    if (!h->p2p_inbox) return fail(h, CDH_BAD_ARG, "cdh_p2p_local_handle must be called first");
+    if (h->comm && (rank != h->rank || nranks != h->nranks))
+        return fail(h, CDH_BAD_ARG, "p2p exchange: rank / nranks differ from the RCCL communicator's");
+    if (h->p2p_ranks) return fail(h, CDH_BAD_ARG, "p2p exchange is already connected");
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int q = 0; q < nranks; ++q) {
+        if (q == rank) { h->p2p_peers.inbox[q] = h->p2p_inbox; continue; }
+        hipIpcMemHandle_t ipc;
+        std::memcpy(&ipc, (const char*)handles_64_bytes_each + 64 * (size_t)q, sizeof ipc);
+        void* mapped = nullptr;
+        HIPCHK(h, hipIpcOpenMemHandle(&mapped, ipc, hipIpcMemLazyEnablePeerAccess));
+        h->p2p_mapped.push_back(mapped);
+        h->p2p_peers.inbox[q] = (unsigned long long*)mapped;
+    }
+    h->rank = rank; h->nranks = nranks; h->p2p_ranks = nranks;
+    if (const char* e = getenv("CDH_P2P_SPIN_LIMIT")) h->p2p_spin_limit = (unsigned)std::max<long long>(1, atoll(e));
+    return CDH_OK;
+}
+
+int32_t cdh_p2p_enable(cdh_handle h, int32_t on) {
+    if (on && !h->p2p_ranks) return fail(h, CDH_BAD_ARG, "p2p exchange is not connected");
+    if (on && *(volatile int*)h->p2p_timeout)
+        return fail(h, CDH_RCCL_ERROR, "p2p exchange timed out earlier on this handle; it stays off");
+    h->p2p_on = on != 0;
+    return CDH_OK;
+}
+
+int32_t cdh_exchange_probe(cdh_handle h, double* inout, int64_t count) {
+    if (count < 0 || count > 4096 || (count > 0 && !inout)) return fail(h, CDH_BAD_ARG, "probe: 0 <= count <= 4096");
+    if (!h->d_red) return fail(h, CDH_BAD_ARG, "probe: handle has no data yet");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_red, inout, sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
+    CHK(allreduce(h, h->d_red, (size_t)count));
+    HIPCHK(h, hipMemcpyAsync(inout, h->d_red, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return p2p_check(h);
 }
 
 int32_t cdh_profile_begin(cdh_handle h) {

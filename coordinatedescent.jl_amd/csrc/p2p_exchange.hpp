@@ -1,0 +1,64 @@
+// p2p_exchange.hpp -- one-shot all-reduce of a short fp64 record over the xGMI full mesh
+// (SURVEY.md section 5): every GPU stores its record into a slot of every peer's inbox, polls its
+// own inbox until all sources have arrived, and sums the sources in rank order -- one hop of
+// latency, all links in parallel, and bit-identical sums on every rank.  OPT-IN (CDH exchange
+// "p2p"): the default exchange is RCCL.  Validated in this pipeline only with two processes on ONE
+// GPU (IPC plumbing, epochs, double buffering); cross-GPU coherence rests on the protocol below.
+//
+// Protocol (the LL idea: data and flag travel in ONE naturally aligned 8-byte store, so no fence
+// and no separate flag can be overtaken): a double is sent as two words {epoch:32 | lo:32} and
+// {epoch:32 | hi:32}, each by one system-scope relaxed atomic store; the reader polls each word with
+// system-scope relaxed atomic loads until its tag equals the epoch.  Inboxes are allocated uncached
+// (hipDeviceMallocUncached) so a poll is never served from a stale L2 line.  Two slots alternate by
+// epoch parity: a rank can start exchange e+1 while a slow peer still reads e, and nobody can reach
+// e+2 (same slot as e) before every rank has finished reading e, because e+1 needs every rank's
+// contribution, which a rank sends only after it has finished e.  Every value is handled by one
+// thread end to end, so the kernel needs no inter-block synchronisation; spins are bounded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cdk {
+
+constexpr int kP2PMaxRanks = 8;
+constexpr int kP2PMaxCount = 2688;                 // >= the widest block record (2625 doubles)
+constexpr int kP2PWords = 2 * kP2PMaxCount;        // 8-byte words per (slot, source)
+constexpr size_t kP2PInboxBytes = (size_t)2 * kP2PMaxRanks * kP2PWords * sizeof(unsigned long long);
+constexpr unsigned kP2PSpinLimit = 20u * 1000u * 1000u;  // default bound, roughly half a minute
+
+struct P2PPeers { unsigned long long* inbox[kP2PMaxRanks]; };
+
+__global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ buf, int count, P2PPeers peers,
+                                                       int rank, int nranks, unsigned epoch,
+                                                       unsigned spin_limit, int* timeout_flag) {
+    // an exchange that already timed out poisons the ones queued behind it: they do not wait again
+    const unsigned limit = *(volatile int*)timeout_flag ? 0u : spin_limit;
+    const size_t slot_off = (size_t)(epoch & 1u) * kP2PMaxRanks * kP2PWords;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < count; v += gridDim.x * blockDim.x) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(buf[v]);
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        const unsigned long long w0 = tag | (bits & 0xffffffffull), w1 = tag | (bits >> 32);
+        for (int q = 0; q < nranks; ++q) {   // my words into slot [rank] of every inbox (mine included)
+            unsigned long long* dst = peers.inbox[q] + slot_off + (size_t)rank * kP2PWords + 2 * (size_t)v;
+            __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        double sum = 0.0;
+        for (int s = 0; s < nranks; ++s) {   // rank order: the same sum on every rank
+            const unsigned long long* src = peers.inbox[rank] + slot_off + (size_t)s * kP2PWords + 2 * (size_t)v;
+            unsigned long long a = 0, b = 0;
+            unsigned spins = 0;
+            for (;;) {
+                a = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                b = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned)(a >> 32) == epoch && (unsigned)(b >> 32) == epoch) break;
+                if (++spins > limit) { *(volatile int*)timeout_flag = 1; break; }   // never hang the GPU
+                __builtin_amdgcn_s_sleep(8);
+            }
+            sum += __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+        }
+        buf[v] = sum;
+    }
+}
+
+}  // namespace cdk

@@ -59,6 +59,16 @@ class ControlPlane:
         self.dist.broadcast(t, src=src)
         return bytes(t.numpy().tobytes())
 
+    def all_gather_bytes(self, payload: bytes) -> bytes:
+        """Concatenation of every rank's equal-length payload, in rank order."""
+        if self.dist is None:
+            return payload
+        import torch
+        mine = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        parts = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        return b"".join(bytes(t.numpy().tobytes()) for t in parts)
+
     def max_over_ranks(self, value: float) -> float:
         if self.dist is None:
             return value
@@ -96,3 +106,51 @@ def connect(loss, cp: ControlPlane):
     uid = cp.broadcast_bytes(uid, 128, src=0)
     loss.comm_init(uid, cp.rank, cp.world)
     return loss
+
+
+def connect_p2p(loss, cp: ControlPlane, selftest: bool = True) -> bool:
+    """OPT-IN direct exchange for the short per-block records (csrc/p2p_exchange.hpp): each
+    rank's inbox is IPC-mapped into every peer, handles travel over the control plane.  With
+    `selftest`, probe records are exchanged and compared with the exact expected sums on every
+    rank; the exchange is enabled only if EVERY stage succeeded on ALL ranks (else the handle
+    stays on RCCL and False is returned).  Collective: every rank must call it, and every rank
+    goes through the same sequence of control-plane collectives whatever fails locally."""
+    import numpy as np
+    if cp.world == 1:
+        return False
+
+    def everyone(ok: bool) -> bool:
+        return cp.sum_over_ranks(1.0 if ok else 0.0) == cp.world
+
+    ok, mine = True, bytes(64)
+    try:
+        mine = loss.p2p_local_handle()
+    except Exception:
+        ok = False
+    handles = cp.all_gather_bytes(mine)
+    if not everyone(ok):
+        return False
+    try:
+        loss.p2p_connect(handles, cp.rank, cp.world)
+    except Exception:
+        ok = False
+    if not everyone(ok):           # also the barrier: every inbox is mapped before anyone stores
+        return False
+    try:
+        loss.p2p_enable(True)
+        if selftest:
+            count, w = 2625, cp.world
+            base = np.arange(count, dtype=np.float64)
+            for rep in range(3):   # three epochs: both slots and the reuse of the first
+                got = loss.exchange_probe((cp.rank + 1) * (base + rep) + 0.25 * cp.rank)
+                want = (w * (w + 1) / 2) * (base + rep) + 0.25 * (w * (w - 1) / 2)
+                ok = ok and bool(np.array_equal(got, want))
+    except Exception:
+        ok = False
+    if not everyone(ok):
+        try:
+            loss.p2p_enable(False)
+        except Exception:
+            pass
+        return False
+    return True

@@ -192,6 +192,20 @@ int32_t cdh_set_use_graph(cdh_handle h, int32_t on);
  * 128 bytes (any transport), every rank calls cdh_comm_init. */
 int32_t cdh_comm_unique_id(void *out_128_bytes);
 int32_t cdh_comm_init(cdh_handle h, const void *id_128_bytes, int32_t rank, int32_t nranks);
+/* Optional direct exchange for the short per-block records (<= 2688 doubles) of a row-sharded
+ * sweep: every rank stores its record into an IPC-mapped inbox on every peer and sums the
+ * sources in rank order (one hop over the xGMI mesh, no ring).  OFF unless connected AND
+ * enabled; longer vectors keep going through RCCL when a communicator exists.
+ *   1. every rank: cdh_p2p_local_handle -> 64 opaque bytes (a HIP IPC memory handle);
+ *   2. all-gather the handles in rank order (any transport), every rank: cdh_p2p_connect;
+ *   3. every rank: cdh_p2p_enable(h, 1)  (collectively: all ranks or none).
+ * A peer that never arrives ends the wait after a bounded spin and the next call on the
+ * handle returns CDH_RCCL_ERROR.  cdh_exchange_probe all-reduces `count` (<= 4096) host
+ * doubles in place through whatever exchange is active (self-test of the transport). */
+int32_t cdh_p2p_local_handle(cdh_handle h, void *out_64_bytes);
+int32_t cdh_p2p_connect(cdh_handle h, const void *handles_64_bytes_each, int32_t rank, int32_t nranks);
+int32_t cdh_p2p_enable(cdh_handle h, int32_t on);
+int32_t cdh_exchange_probe(cdh_handle h, double *inout, int64_t count);
 /* HIP-event timing of the sweep kernels on the handle's stream: everything
  * launched by cdh_pass / cdh_solve between begin and end.  out_launches counts
  * the dominant (column-streaming) kernel launches, out_ms the event time they

@@ -1,0 +1,63 @@
+"""Worker of test_gpu_parity.py::test_p2p_exchange_two_ranks_one_gpu (run under
+torch.distributed.run, 2 ranks, BOTH on cuda:0).  Each rank holds a row shard; the only exchange
+is the opt-in direct exchange of csrc/p2p_exchange.hpp (RCCL refuses two ranks on one device, so
+no communicator exists and longer vectors are chunked through the same inboxes).  Checks: the
+transport self-test, beta against the oracle's unsharded solve (1e-10), and bit-identical beta on
+the two ranks.  Prints P2P_OK from rank 0."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import coordinatedescent_jl_amd as cd  # noqa: E402
+from coordinatedescent_jl_amd import sharded  # noqa: E402
+import oracle  # noqa: E402  (the checker)
+
+
+def main():
+    cp = sharded.ControlPlane(backend="gloo")
+    assert cp.world == 2
+    n, p = 60000, 150
+    rng = np.random.default_rng(17)
+    X = rng.standard_normal((n, p))
+    beta0 = np.zeros(p)
+    beta0[:12] = rng.standard_normal(12) * 2
+    y = X @ beta0 + rng.standard_normal(n)
+    row0, nl = sharded.shard_rows(n, cp.rank, cp.world)
+    lam = 0.05
+    opt = cd.CDOptions(randomize=False, optTol=1e-11, maxIter=500)
+    xo = oracle.SparseIterate(p)
+    fo = oracle.CDLeastSquaresLoss(y, X)
+    oracle.coordinateDescent_(xo, fo, oracle.ProxL1(lam), oracle.CDOptions(randomize=False, optTol=1e-11, maxIter=500))
+    want = xo.dense()
+    for mode, block in (("coord", 0), ("block", 16), ("block", 64)):
+        f = cd.CDLeastSquaresLoss(y[row0:row0 + nl], X[row0:row0 + nl], device=0, n_total=n, row_offset=row0)
+        assert sharded.connect_p2p(f, cp, selftest=True), "p2p self-test failed"
+        if mode == "block":
+            f.set_sweep_mode("block", block)
+        else:
+            f.set_sweep_mode("coord")
+        x = cd.SparseIterate(p)
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), opt)
+        got = x.dense()
+        err = float(np.max(np.abs(got - want)))
+        assert err < 1e-10, (mode, block, err)
+        both = np.frombuffer(cp.all_gather_bytes(got.tobytes()), dtype=np.float64).reshape(2, p)
+        assert np.array_equal(both[0], both[1]), "ranks disagree"
+        lm = cd.findLambdaMax(cd.SparseIterate(p), f, cd.ProxL1(1.0))
+        lo = oracle.findLambdaMax(oracle.SparseIterate(p), fo, oracle.ProxL1(1.0))
+        assert abs(lm - lo) < 1e-12 * max(1.0, lo), (lm, lo)
+        # longer than one inbox slot and no communicator: chunked through the same inboxes
+        v = np.arange(4096, dtype=np.float64) * (1 + cp.rank)
+        assert np.array_equal(f.exchange_probe(v), 3.0 * np.arange(4096, dtype=np.float64))
+        cp.barrier()
+        del f
+    if cp.rank == 0:
+        print("P2P_OK")
+    cp.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -420,6 +420,23 @@ def test_rccl_path_under_torchrun_matches_plain_run(mode_args):
     assert ja["config"]["moved_per_sweep"] == jb["config"]["moved_per_sweep"]
 
 
+# ---- the opt-in direct exchange (csrc/p2p_exchange.hpp): two ranks, both on cuda:0, row shards,
+# IPC-mapped inboxes, no RCCL at all.  This is what a one-GPU box can validate of it: the handle
+# plumbing, epochs / slot reuse, chunking, and the sharded arithmetic end to end against the oracle.
+def test_p2p_exchange_two_ranks_one_gpu():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29950 + (os.getpid() % 40)
+    env = dict(os.environ, CDH_P2P_SPIN_LIMIT="4000000")     # a failure must not take minutes
+    a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "tests", "p2p_worker.py")],
+                       capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert a.returncode == 0, (a.stdout[-1500:], a.stderr[-3000:])
+    assert "P2P_OK" in a.stdout
+
+
 # ---- section 8(f) rows: screening init kept on the device, LassoPath without the rebuild ---------
 def test_gram_entry_point_matches_numpy():
     rng, X, Y = _problem(31, 5003, 80, 6)

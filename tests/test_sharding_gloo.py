@@ -44,6 +44,8 @@ def _worker(rank, world, port, n, p, lam, out):
     assert cp.broadcast_bytes(blob, 128) == bytes(range(128))
     assert cp.max_over_ranks(float(rank)) == world - 1
     assert cp.sum_over_ranks(1.0) == world
+    # rank-ordered gather (the IPC handles of the opt-in direct exchange travel this way)
+    assert cp.all_gather_bytes(bytes([rank]) * 64) == b"".join(bytes([q]) * 64 for q in range(world))
     # row-sharded coordinate descent with a real all-reduce per coordinate
     rng = np.random.default_rng(5)
     X = rng.standard_normal((n, p))
