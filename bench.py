@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--exchange", default=os.environ.get("CDH_EXCHANGE", "rccl"), choices=["rccl", "p2p"],
                     help="exchange of the timed region when sharded (p2p: opt-in direct exchange, falls back "
                          "to rccl if its self-test fails)")
+    ap.add_argument("--no-rccl", action="store_true",
+                    help="TEST ONLY (ranks sharing one GPU, which RCCL refuses): build no communicator; with "
+                         "--exchange rccl the timed region then has NO exchange and its numbers mean nothing")
     ap.add_argument("--no-exchange-trial", action="store_true",
                     help="sharded runs: skip the untimed trial of the other exchange after the timed region")
     a = ap.parse_args()
@@ -137,8 +140,11 @@ def main():
 
     f, bstar = cd.CDLeastSquaresLoss.generate(n_local, a.cols, seed=123, s=a.planted, noise=a.noise, dtype=dtype,
                                               device=device, n_total=a.rows, row_offset=row0)
-    sharded.connect(f, cp)
     exchange = "rccl"
+    if a.no_rccl:
+        exchange = "none(test-only)"
+    else:
+        sharded.connect(f, cp)
     if cp.world > 1 and a.exchange == "p2p" and sharded.connect_p2p(f, cp):
         exchange = "p2p"
     if a.block is None:
@@ -198,7 +204,7 @@ def main():
     # of `value`).  Local failures are caught; the only control-plane collectives are the ones every
     # rank reaches (connect_p2p's and the two reductions below).
     trial = None
-    if cp.world > 1 and exchange == "rccl" and not a.no_exchange_trial:
+    if cp.world > 1 and exchange != "p2p" and not a.no_exchange_trial:
         trial, t_loc, ok_loc, err_loc = {"exchange": "p2p"}, 0.0, False, 0.0
         try:
             connected = sharded.connect_p2p(f, cp)

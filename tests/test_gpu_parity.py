@@ -437,6 +437,44 @@ def test_p2p_exchange_two_ranks_one_gpu():
     assert "P2P_OK" in a.stdout
 
 
+def _bench_two_ranks_one_gpu(extra):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29900 + (os.getpid() % 40)
+    env = dict(os.environ, CDH_P2P_SPIN_LIMIT="4000000")
+    cmd = ["--steps", "2", "--warmup", "1", "--rows", "300000", "--cols", "96", "--planted", "10",
+           "--no-cpu-baseline", "--no-sparse", "--block", "16"]
+    a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--no-rccl"] + cmd + extra,
+                       capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert a.returncode == 0, (a.stdout[-1500:], a.stderr[-3000:])
+    b = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + cmd,
+                       capture_output=True, text=True, timeout=420, cwd=root)
+    assert b.returncode == 0, b.stderr[-2000:]
+    last = lambda out: json.loads([l for l in out.splitlines() if l.startswith("{")][-1])  # noqa: E731
+    return last(a.stdout), last(b.stdout)
+
+
+def test_bench_sharded_with_p2p_exchange_two_ranks_one_gpu():
+    """bench.py's N>1 flow with the direct exchange in the timed region: same sweep as one rank."""
+    ja, jb = _bench_two_ranks_one_gpu(["--exchange", "p2p"])
+    assert ja["n_gpus"] == 2 and ja["config"]["exchange"] == "p2p" and "exchange_trial" not in ja
+    assert ja["config"]["moved_per_sweep"] == jb["config"]["moved_per_sweep"]
+    assert abs(ja["config"]["last_maxH"] - jb["config"]["last_maxH"]) <= 1e-9 * abs(jb["config"]["last_maxH"])
+
+
+def test_bench_exchange_trial_code_path_two_ranks_one_gpu():
+    """The guarded trial bench.py runs after an RCCL-timed region, exercised without RCCL (--no-rccl:
+    the timed region has no exchange, so only the trial's own fields are meaningful here)."""
+    ja, _ = _bench_two_ranks_one_gpu([])
+    t = ja["exchange_trial"]
+    assert t["selftest"] is True and t["completed_on_all_ranks"] is True and t["ms_per_step"] > 0
+    assert "error" not in t
+
+
 # ---- section 8(f) rows: screening init kept on the device, LassoPath without the rebuild ---------
 def test_gram_entry_point_matches_numpy():
     rng, X, Y = _problem(31, 5003, 80, 6)
