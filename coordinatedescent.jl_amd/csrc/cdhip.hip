@@ -29,6 +29,7 @@ constexpr int kMaxStepGrid = 2048;   // blocks of k_step (8 per CU on 256 CUs)
 constexpr int kBlockGridPerCU = 4;   // upper bound of k_blockstep blocks per CU (partials sizing)
 constexpr int kColChunks = 64;       // row chunks per column in k_col_dots
 constexpr int kMaxBlockB = 8;
+constexpr int kShortRounds = 16;     // below this many rounds of 64-vector chunks per launch: short chunks
 
 // ---- RCCL through dlopen: only multi-process runs need it ------------------------
 struct Rccl {
@@ -107,6 +108,7 @@ struct cdh_handle_s {
     int step_grid = 1, block_grid = 1, gram_grid = 1, cus = 1, gram32_per_cu = 1;
     int64_t gram_units = 1;
     bool nt = true;  // non-temporal loads for the X column streams
+    int ks = 0;      // chunk length of the LDS-transposed path: 0 by shard length, 1 short, 2 long (env CDH_KS)
     int lt = 2;      // coalesced operand loads transposed through LDS: 0 off, 1 on, 2 by size (default)
     // comm
     void* comm = nullptr;
@@ -334,10 +336,24 @@ template <typename T, int NG> int32_t launch_gram_chunk(cdh_handle h, int m) {
         // width; at 1.25e6 rows neutral for B = 64 and +5 % for B = 32, so the narrower widths take
         // it only on long columns.  fp32 B = 64 would spill: fragment path.
         const bool use_lt = h->lt == 1 || (h->lt == 2 && (NG == 4 || h->n >= 2000000));
+        // short columns (a launch is fewer than kShortRounds rounds of 64-vector chunks): chunks of
+        // one sub-chunk, so a partly filled last round costs a quarter (B = 64) or half (B = 32) as much
+        const int64_t rounds64 = ((h->nvec + 63) / 64) / ((int64_t)G * kGramWaves);
+        const bool short_chunks = h->ks == 1 || (h->ks == 0 && rounds64 < kShortRounds);
+        bool launched = false;
         if (use_lt && !(NG == 4 && sizeof(T) == 4)) {
-            hipLaunchKernelGGL((k_gramstep<T, NG, true, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
-                               (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb,
-                               nprev, h->d_partials);
+            if constexpr (NG >= 2) {
+                if (short_chunks) {
+                    hipLaunchKernelGGL((k_gramstep<T, NG, true, true, 1>), dim3(G), dim3(64 * kGramWaves), 0,
+                                       h->stream, (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs,
+                                       pos0, nb, nprev, h->d_partials);
+                    launched = true;
+                }
+            }
+            if (!launched)
+                hipLaunchKernelGGL((k_gramstep<T, NG, true, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
+                                   (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb,
+                                   nprev, h->d_partials);
         } else if (h->nt)
             hipLaunchKernelGGL((k_gramstep<T, NG, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
                                (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
@@ -683,6 +699,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         auto env_int = [](const char* nm, int dflt) { const char* v = getenv(nm); return v ? atoi(v) : dflt; };
         h->nt = env_int("CDH_NT", 1) != 0;
         h->lt = env_int("CDH_LT", 2);
+        h->ks = env_int("CDH_KS", 0);
         const int step_per_cu = std::max(1, env_int("CDH_STEP_GRID_PER_CU", 8));
         const int block_per_cu = std::max(1, std::min(kBlockGridPerCU, env_int("CDH_BLOCK_GRID_PER_CU", 3)));
         const int64_t want = (h->nvec + (int64_t)kBlock * kUnroll - 1) / ((int64_t)kBlock * kUnroll);

@@ -67,7 +67,14 @@ template <int NG> struct LtTile {
     static constexpr int SLOTS = 16 * NG * XS;
 };
 
-template <typename T, int NG, bool NT_, bool LT = false>
+//
+// KS (LT only): sub-chunks per wave iteration.  KS = NG is the 64-vector chunk; KS = 1 makes the
+// chunk ONE sub-chunk (64/NG vectors) for short columns, where a launch is only a few rounds of
+// chunks long and a partly filled last round costs a whole round (measured at 1.25e6 rows, B = 64:
+// 4.2 .. 5.0 rounds all take the time of 5).  Phase A then runs on a 2-D lane layout: NG/KS
+// column groups x chunk vectors, one load instruction covering NG/KS previous columns, the column
+// groups summed by a butterfly.
+template <typename T, int NG, bool NT_, bool LT = false, int KS = NG>
 __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gramstep(
     const T* __restrict__ X, int64_t ld, int64_t nvec, const T* __restrict__ w, T* __restrict__ r,
     const int64_t* __restrict__ idx, const double* __restrict__ hs, int pos0, int nb, int nprev,
@@ -153,46 +160,63 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
     for (int t = 0; t < NG; ++t) { cacc[t] = 0.0; ctile[t] = dvec4{0.0, 0.0, 0.0, 0.0}; }
     double qacc = 0.0;
 
-    const int64_t nchunks = (nvec + 63) >> 6;
+    static_assert(KS == NG || (LT && KS == 1), "short chunks need the LDS-transposed operand path");
+    constexpr int CVN = LT ? LtTile<NG>::SV * KS : 64;   // vectors per chunk
+    constexpr int CGN = 64 / CVN;                         // phase-A column groups
+    const int pa_cg = lane / CVN, pa_v = lane % CVN;
+    const int64_t nchunks = (nvec + CVN - 1) / CVN;
     // chunk -> (block, wave): the block index runs fastest, so consecutive chunks go to different
     // blocks and no block gets more than one chunk above any other (a block-major split would
     // hand the last partial round to a few blocks, four chunks each: ~10 % tail at 1e6 rows)
     for (int64_t ch = (int64_t)wave * gridDim.x + blockIdx.x; ch < nchunks;
          ch += (int64_t)gridDim.x * kGramWaves) {
-        const int64_t v0 = ch << 6;
-        // ---- phase A (coalesced): r' = r - sum_i h_i X_prev,i on this wave's 64 vectors -------
-        const int64_t jv = v0 + lane;
+        const int64_t v0 = ch * CVN;
+        // ---- phase A (coalesced): r' = r - sum_i h_i X_prev,i on this wave's chunk vectors -----
+        const int64_t jv = v0 + pa_v;
         const bool inb = jv < nvec;
-        V rr = inb ? rv[jv] : vzero((V*)nullptr);
+        V rr = (inb && pa_cg == 0) ? rv[jv] : vzero((V*)nullptr);
         if (anyp) {
             double re[NV];
 #pragma unroll
             for (int e = 0; e < NV; ++e) re[e] = (double)rr[e];
             constexpr int PG = (LT && NG == 4) ? 8 : CDH_PG(NG);   // independent loads in flight per group
-            for (int i0 = 0; i0 < nzp; i0 += PG) {
+            for (int i0 = 0; i0 < nzp; i0 += PG * CGN) {
                 V xp[PG];
 #pragma unroll
                 for (int t = 0; t < PG; ++t) {
-                    const int ii = (i0 + t < nzp) ? i0 + t : nzp - 1;
+                    const int at = i0 + t * CGN + pa_cg;
+                    const int ii = (at < nzp) ? at : nzp - 1;
                     xp[t] = inb ? ld_stream<NT_>(reinterpret_cast<const V*>(X + s_kp[ii] * ld) + jv)
                                 : vzero((V*)nullptr);
                 }
 #pragma unroll
                 for (int t = 0; t < PG; ++t) {
-                    const double h = (i0 + t < nzp) ? s_hp[i0 + t] : 0.0;
+                    const int at = i0 + t * CGN + pa_cg;
+                    const double h = (at < nzp) ? s_hp[at] : 0.0;
 #pragma unroll
                     for (int e = 0; e < NV; ++e) re[e] = fma(-h, (double)xp[t][e], re[e]);
                 }
             }
+            if constexpr (CGN > 1) {   // sum the column groups: every lane ends with the full r'
+#pragma unroll
+                for (int off = CVN; off < 64; off <<= 1)
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) re[e] += __shfl_xor(re[e], off);
+            }
 #pragma unroll
             for (int e = 0; e < NV; ++e) rr[e] = (T)re[e];
-            if (inb) rv[jv] = rr;
-        }
+            if (inb && pa_cg == 0) rv[jv] = rr;
+        } else if constexpr (CGN > 1) {
 #pragma unroll
-        for (int e = 0; e < NV; ++e) qacc = fma((double)rr[e], (double)rr[e], qacc);
+            for (int e = 0; e < NV; ++e) rr[e] = (T)__shfl((double)rr[e], pa_v);   // group 0 holds r
+        }
+        if (pa_cg == 0) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) qacc = fma((double)rr[e], (double)rr[e], qacc);
+        }
         __builtin_amdgcn_wave_barrier();
-        s_r[wave][lane] = rr;
-        if (w) s_w[wave][lane] = inb ? reinterpret_cast<const V*>(w)[jv] : vzero((V*)nullptr);
+        s_r[wave][pa_v] = rr;   // the column groups hold (and write) the same value
+        if (w) s_w[wave][pa_v] = inb ? reinterpret_cast<const V*>(w)[jv] : vzero((V*)nullptr);
         __builtin_amdgcn_wave_barrier();
         // ---- phase B: tiles += X_I' X_J, X_I' r' over the chunk's rows, in UH-sized groups of
         // fragment loads (16/NG vector rows at a time so the kernel fits 2 waves per SIMD: the
@@ -209,7 +233,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
         // not unrolled: one group's fragment loads in flight at a time keeps the register
         // footprint at 2-3 waves per SIMD (unrolled, the scheduler hoists every group's loads)
 #pragma unroll 1
-        for (int u0 = 0; u0 < 16; u0 += UH) {
+        for (int u0 = 0; u0 < (LT ? UH * KS : 16); u0 += UH) {
             V xf[UH][NG];
             if constexpr (LT) {
                 constexpr int SV = LtTile<NG>::SV, XS = LtTile<NG>::XS;

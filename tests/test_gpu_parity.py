@@ -390,6 +390,35 @@ def test_edge_shapes_and_repeated_coordinates(mode):
     assert cd.cdPass_(x, f, g, []) == 0.0
 
 
+# ---- every operand path of the wide-block kernel (csrc/gram_kernels.hpp): fragment loads, LDS-
+# transposed loads with 64-vector chunks, and with one-sub-chunk chunks (short columns).  The library
+# picks by shard length; the knobs (read when a handle is created) pin each one here. ----------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("knobs", [{"CDH_LT": "0"}, {"CDH_LT": "1", "CDH_KS": "2"}, {"CDH_LT": "1", "CDH_KS": "1"}],
+                         ids=["fragment", "lt_long", "lt_short"])
+@pytest.mark.parametrize("block", [16, 32, 64])
+def test_wide_block_operand_paths(monkeypatch, block, knobs, dtype):
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    rng, X, Y = _problem(77, 9001, 70, 8)            # ragged rows, a ragged last block (70 = 64 + 6)
+    w = rng.uniform(0.5, 2.0, size=9001)
+    lam = 0.05
+    o = dict(maxIter=400, optTol=1e-12 if dtype == np.float64 else 1e-6, randomize=False)
+    for weighted in (False, True):
+        if weighted:
+            f = cd.CDWeightedLSLoss(Y.astype(dtype), X.astype(dtype), w.astype(dtype))
+            fo = O.CDWeightedLSLoss(Y, X, w)
+        else:
+            f = cd.CDLeastSquaresLoss(Y.astype(dtype), X.astype(dtype))
+            fo = O.CDLeastSquaresLoss(Y, X)
+        f.set_sweep_mode("block", block)
+        x, xo = cd.SparseIterate(70), O.SparseIterate(70)
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+        O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(maxIter=400, optTol=1e-12, randomize=False))
+        tol = BETA_TOL if dtype == np.float64 else 2e-4    # fp32 storage against the fp64 oracle
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=tol)
+
+
 # ---- the multi-process code path on one GPU: torch.distributed.run + a forced 1-rank RCCL
 # communicator (dlopen of librccl, ncclCommInitRank, ncclAllReduce on the sweep stream between the
 # reduce and the scalar kernels).  RCCL refuses two ranks on one device, so this is as far as a
