@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default=os.environ.get("CDH_BENCH_MODE", "block"), choices=["coord", "block"])
     ap.add_argument("--block", type=int, default=None, choices=[2, 4, 8, 16, 32, 64],
-                    help="visits per launch of the blocked sweep (default 16 on one GPU, 64 sharded: "
+                    help="visits per launch of the blocked sweep (default 32 on one GPU, 64 sharded: "
                          "half the exchanges per sweep)")
     ap.add_argument("--graph", action="store_true", help="replay each pass from a captured hipGraph")
     ap.add_argument("--lam-frac", type=float, default=1e-6, help="lambda / lambda_max")
@@ -148,7 +148,7 @@ def main():
     if cp.world > 1 and a.exchange == "p2p" and sharded.connect_p2p(f, cp):
         exchange = "p2p"
     if a.block is None:
-        a.block = 16 if cp.world == 1 else 64
+        a.block = 32 if cp.world == 1 else 64
     f.set_sweep_mode(a.mode, a.block)
     f.set_use_graph(a.graph)
     x = cd.SparseIterate(a.cols)

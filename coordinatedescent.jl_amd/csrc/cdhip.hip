@@ -105,7 +105,8 @@ struct cdh_handle_s {
     std::vector<int32_t> stamp;   // duplicate detection scratch, size p
     std::vector<std::pair<uint64_t, hipGraphExec_t>> graphs;  // captured chunk launch sequences
     bool domain_error = false;
-    int step_grid = 1, block_grid = 1, gram_grid = 1, cus = 1, gram32_per_cu = 1;
+    int step_grid = 1, block_grid = 1, gram_per_cu = 2, cus = 1, gram32_per_cu = 1;
+    int lt_per_cu = 0;  // experiments: blocks per CU of the LDS-transposed variants (0 = by tile size)
     int64_t gram_units = 1;
     bool nt = true;  // non-temporal loads for the X column streams
     int ks = 0;      // chunk length of the LDS-transposed path: 0 by shard length, 1 short, 2 long (env CDH_KS)
@@ -314,54 +315,52 @@ template <typename T, int B> int32_t launch_block_chunk(cdh_handle h, int m) {
     return CDH_OK;
 }
 
-// blocks of k_gramstep<NG>: as many as stay resident (B = 64 holds 2 waves per SIMD, the narrower
-// ones 3), never more than the partial buffer was sized for
-inline int NGgrid(cdh_handle h, int NG) {
-    const int per_cu = NG == 4 ? std::min(h->gram32_per_cu, 2) : h->gram32_per_cu;
-    return NG >= 2 ? balanced_grid(h->gram_units, (int64_t)h->cus * per_cu) : h->gram_grid;
+// blocks of k_gramstep per CU: as many as stay resident for the variant launched (register
+// footprint: B = 64 holds 2 waves per SIMD, the narrower ones 3; the LDS-transposed variants are
+// bounded by their 68-78 KB operand tiles to 2 blocks -- B = 32 launched with 3 per CU ran its
+// third of the grid as a second, half-empty round: 933 -> 861 us per block at 1e7 rows), never
+// more than the partial buffer was sized for
+inline int gram_blocks_per_cu(cdh_handle h, int NG, bool lt) {
+    if (lt) return h->lt_per_cu > 0 ? h->lt_per_cu : 2;
+    return NG == 4 ? std::min(h->gram32_per_cu, 2) : NG == 2 ? h->gram32_per_cu : h->gram_per_cu;
+}
+inline int NGgrid(cdh_handle h, int NG, bool lt = false) {
+    return balanced_grid(h->gram_units, (int64_t)h->cus * gram_blocks_per_cu(h, NG, lt));
 }
 
-// wide blocks (B = 16 / 32): MFMA-accumulated Gram kernel + two-stage reduction
+// wide blocks (B = 16 / 32 / 64): MFMA-accumulated Gram kernel + two-stage reduction
 template <typename T, int NG> int32_t launch_gram_chunk(cdh_handle h, int m) {
     using R = GramRec<NG>;
     constexpr int B = R::B;
-    // blocks per CU follow the kernel's register footprint (2 waves per SIMD for both widths)
-    const int G = NGgrid(h, NG);
-    if ((size_t)G * R::N > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partial buffer too small for this grid");
     const T* wts = h->has_w ? (const T*)h->w : (const T*)nullptr;
+    // LDS-transposed (fully coalesced) operand loads: measured -5 % at >= 5e6 rows for every
+    // width; with short chunks also -10 % for B = 32 at 6.25e5 .. 1.25e6 rows and neutral for
+    // B = 64.  B = 16 takes it on long columns only.  fp32 B = 64 would spill: fragment path.
+    const bool use_lt = (h->lt == 1 || (h->lt == 2 && (NG >= 2 || h->n >= 2000000))) && !(NG == 4 && sizeof(T) == 4);
+    const int G = NGgrid(h, NG, use_lt);
+    if ((size_t)G * R::N > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partial buffer too small for this grid");
+    // short columns (a launch is fewer than kShortRounds rounds of 64-vector chunks): chunks of
+    // one sub-chunk, so a partly filled last round costs a quarter (B = 64) or half (B = 32) as much
+    const int64_t rounds64 = ((h->nvec + 63) / 64) / ((int64_t)G * kGramWaves);
+    const bool short_chunks = use_lt && (h->ks == 1 || (h->ks == 0 && rounds64 < kShortRounds));
     int nprev = 0;
     for (int pos0 = 0; pos0 < m; pos0 += B) {
         const int nb = std::min(B, m - pos0);
-        // LDS-transposed (fully coalesced) operand loads: measured -5 % at >= 5e6 rows for every
-        // width; at 1.25e6 rows neutral for B = 64 and +5 % for B = 32, so the narrower widths take
-        // it only on long columns.  fp32 B = 64 would spill: fragment path.
-        const bool use_lt = h->lt == 1 || (h->lt == 2 && (NG == 4 || h->n >= 2000000));
-        // short columns (a launch is fewer than kShortRounds rounds of 64-vector chunks): chunks of
-        // one sub-chunk, so a partly filled last round costs a quarter (B = 64) or half (B = 32) as much
-        const int64_t rounds64 = ((h->nvec + 63) / 64) / ((int64_t)G * kGramWaves);
-        const bool short_chunks = h->ks == 1 || (h->ks == 0 && rounds64 < kShortRounds);
-        bool launched = false;
-        if (use_lt && !(NG == 4 && sizeof(T) == 4)) {
-            if constexpr (NG >= 2) {
-                if (short_chunks) {
-                    hipLaunchKernelGGL((k_gramstep<T, NG, true, true, 1>), dim3(G), dim3(64 * kGramWaves), 0,
-                                       h->stream, (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs,
-                                       pos0, nb, nprev, h->d_partials);
-                    launched = true;
-                }
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(G), dim3(64 * kGramWaves), 0, h->stream, (const T*)h->X, h->ld, h->nvec,
+                               wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev, h->d_partials);
+        };
+        if (use_lt) {
+            if constexpr (NG == 1) {
+                go(k_gramstep<T, 1, true, true>);
+            } else {
+                if (short_chunks) go(k_gramstep<T, NG, true, true, 1>); else go(k_gramstep<T, NG, true, true>);
             }
-            if (!launched)
-                hipLaunchKernelGGL((k_gramstep<T, NG, true, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
-                                   (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb,
-                                   nprev, h->d_partials);
-        } else if (h->nt)
-            hipLaunchKernelGGL((k_gramstep<T, NG, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
-                               (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
-                               h->d_partials);
-        else
-            hipLaunchKernelGGL((k_gramstep<T, NG, false>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
-                               (const T*)h->X, h->ld, h->nvec, wts, (T*)h->r, h->d_idx, h->d_hs, pos0, nb, nprev,
-                               h->d_partials);
+        } else if (h->nt) {
+            go(k_gramstep<T, NG, true>);
+        } else {
+            go(k_gramstep<T, NG, false>);
+        }
         hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + 3) / 4), dim3(256), 0, h->stream, h->d_partials, G, R::N, h->d_red);  // one value per wave
         CHK(allreduce(h, h->d_red, R::N));
         hipLaunchKernelGGL((k_gram_scalar<NG>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb, h->chunk_dup ? 1 : 0, h->d_ctrl,
@@ -709,7 +708,8 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->cus = cus;
         h->gram32_per_cu = std::max(1, env_int("CDH_GRAM32_GRID_PER_CU", 3));
         const int64_t wantg = (h->nvec + 64 * kGramWaves - 1) / (64 * kGramWaves);
-        h->gram_grid = balanced_grid(wantg, (int64_t)cus * std::max(1, env_int("CDH_GRAM_GRID_PER_CU", 2)));
+        h->gram_per_cu = std::max(1, std::min(4, env_int("CDH_GRAM_GRID_PER_CU", 2)));
+        h->lt_per_cu = std::max(0, std::min(4, env_int("CDH_LT_PER_CU", 0)));
         h->gram_units = wantg;
         const size_t colbytes = (size_t)h->ld * h->esz;
         HIPCHK(h, hipMalloc(&h->X, colbytes * (size_t)p));
@@ -733,8 +733,8 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
                                                 (size_t)cus * kBlockGridPerCU * BlockRec<kMaxBlockB>::N,
                                                 (size_t)4096 * kColChunks * 2,
                                                 (size_t)cus * 2 * GramRec<4>::N,
-                                                (size_t)cus * std::max(h->gram32_per_cu, 3) * GramRec<2>::N,
-                                                (size_t)cus * std::max(env_int("CDH_GRAM_GRID_PER_CU", 2), 3) * GramRec<1>::N});
+                                                (size_t)cus * std::max(h->gram32_per_cu, 4) * GramRec<2>::N,
+                                                (size_t)cus * 4 * GramRec<1>::N});
         HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * h->partials_doubles));
         HIPCHK(h, hipMalloc(&h->d_red, sizeof(double) * 4096));
         HIPCHK(h, hipMalloc(&h->d_colout, sizeof(double) * 2 * p));

@@ -61,6 +61,8 @@ constexpr int kGramWaves = 4;  // waves per block
 // lines), and the wave's 64-vector chunk is consumed in NG sub-chunks.  Column stride = run + pad
 // slots of 16 B; pad 2 makes the ds_read_b128 fragment reads conflict-free, B = 64 takes pad 1 (one
 // 2-way pair) to keep a block under 80 KB of LDS = 2 blocks per CU.
+// (Measured and dropped: B = 16 with half / quarter tiles -- load instructions covering 2 / 4 columns,
+// 3 / 4 blocks per CU instead of 2 -- is no faster at 5e6 .. 1e7 rows; occupancy is not the limit.)
 template <int NG> struct LtTile {
     static constexpr int SV = 64 / NG;                    // vectors per sub-chunk
     static constexpr int XS = SV + (NG == 4 ? 1 : 2);     // column stride in 16-B slots
@@ -88,7 +90,8 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
     __shared__ double s_hp[B];
     __shared__ int64_t s_kp[B];
     __shared__ double s_q[kGramWaves];
-    __shared__ V s_x[LT ? kGramWaves : 1][LT ? LtTile<NG>::SLOTS : 1];
+    using LTT = LtTile<NG>;
+    __shared__ V s_x[LT ? kGramWaves : 1][LT ? LTT::SLOTS : 1];
     // end-of-kernel cross-wave reduction, per tile; with LT it reuses the (then idle) operand
     // tiles so the block stays under 80 KB of LDS = 2 blocks per CU
     __shared__ double s_red_own[LT ? 1 : kGramWaves][LT ? 1 : 256];
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
     V* __restrict__ rv = reinterpret_cast<V*>(r);
     // LT: load instruction t of a sub-chunk covers columns t*NG .. t*NG+NG-1; this lane takes
     // column t*NG + lt_cl at vector lt_vl of the sub-chunk
-    const int lt_cl = lane / LtTile<NG>::SV, lt_vl = lane % LtTile<NG>::SV;
+    const int lt_cl = lane / LTT::SV, lt_vl = lane % LTT::SV;
     const V* lt_col[LT ? 16 : 1];
     unsigned lt_act = 0;
     if constexpr (LT) {
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
     double qacc = 0.0;
 
     static_assert(KS == NG || (LT && KS == 1), "short chunks need the LDS-transposed operand path");
-    constexpr int CVN = LT ? LtTile<NG>::SV * KS : 64;   // vectors per chunk
+    constexpr int CVN = LT ? LTT::SV * KS : 64;   // vectors per chunk
     constexpr int CGN = 64 / CVN;                         // phase-A column groups
     const int pa_cg = lane / CVN, pa_v = lane % CVN;
     const int64_t nchunks = (nvec + CVN - 1) / CVN;
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
         // ---- phase B: tiles += X_I' X_J, X_I' r' over the chunk's rows, in UH-sized groups of
         // fragment loads (16/NG vector rows at a time so the kernel fits 2 waves per SIMD: the
         // other wave's loads then overlap this wave's MFMA phase) ------------------------------------
-        constexpr int UH = LT ? 16 / NG : CDH_UH(NG);
+        constexpr int UH = LT ? LTT::SV / 4 : CDH_UH(NG);
         fvec4 t32[R::NT], ct32[NG];
         float c32[NG];
         if constexpr (F32) {
@@ -236,22 +239,21 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
         for (int u0 = 0; u0 < (LT ? UH * KS : 16); u0 += UH) {
             V xf[UH][NG];
             if constexpr (LT) {
-                constexpr int SV = LtTile<NG>::SV, XS = LtTile<NG>::XS;
-                V xc[16];
+                constexpr int XS = LTT::XS, NL = 16;
+                V xc[NL];
                 const int64_t vsub = v0 + 4 * u0 + lt_vl;       // this lane's vector in the sub-chunk
 #pragma unroll
-                for (int t = 0; t < 16; ++t)
+                for (int t = 0; t < NL; ++t)
                     xc[t] = (((lt_act >> t) & 1) && vsub < nvec) ? ld_stream<NT_>(lt_col[t] + vsub)
                                                                  : vzero((V*)nullptr);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int t = 0; t < 16; ++t) s_x[wave][(t * NG + lt_cl) * XS + lt_vl] = xc[t];
+                for (int t = 0; t < NL; ++t) s_x[wave][(t * NG + lt_cl) * XS + lt_vl] = xc[t];
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int u = 0; u < UH; ++u)
 #pragma unroll
                     for (int grp = 0; grp < NG; ++grp) xf[u][grp] = s_x[wave][(16 * grp + c) * XS + 4 * u + g];
-                (void)SV;
             } else {
 #pragma unroll
                 for (int u = 0; u < UH; ++u) {
