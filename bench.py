@@ -148,7 +148,8 @@ def main():
     if cp.world > 1 and a.exchange == "p2p" and sharded.connect_p2p(f, cp):
         exchange = "p2p"
     if a.block is None:
-        a.block = 32 if cp.world == 1 else 64
+        # fp32 B = 64 has no LDS-transposed variant (it would spill) and runs far below B = 32
+        a.block = 32 if (cp.world == 1 or a.dtype == "f32") else 64
     f.set_sweep_mode(a.mode, a.block)
     f.set_use_graph(a.graph)
     x = cd.SparseIterate(a.cols)
