@@ -421,7 +421,8 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
     const int64_t k_me = idx[pos0 + li];
     double gcol[B];
 #pragma unroll
-    for (int s = 0; s < B; ++s) gcol[s] = rec_g[R::g(s < li ? s : li, li)];   // G[s][li], s < li
+    for (int s = 0; s < B; ++s)   // G[s][li] for s < li; 0 after the lane's own visit, which freezes b_me there
+        gcol[s] = (s < li) ? rec_g[R::g(s < li ? s : li, li)] : 0.0;
     double b_me = rec_g[R::OFF_C + li];
     const double a_me = rec_g[R::g(li, li)];
     double q = rec_g[R::OFF_Q];
@@ -434,6 +435,26 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
     const double thr_me = lambda0 * om_me * (n_total * ia_me);
     int dom = 0;
     double v_me = 0.0, nv_me = 0.0, h_me = 0.0;
+    if (loss != 1 && !dup) {
+        // least squares, no repeated coordinate (every scheduler-made pass): the chain is fma ->
+        // soft-threshold -> subtract -> broadcast -> fma and nothing else.  Lanes outside the block
+        // never move (threshold = inf); b stays frozen after a lane's own visit (zeros in gcol), so
+        // each lane recomputes its own visit after the loop instead of latching it inside.
+        const double inf = __builtin_huge_val();
+        const double ia_f = mine ? ia_me : 0.0, thr_f = mine ? thr_me : inf, old_f = mine ? old_me : 0.0;
+        double b_f = mine ? b_me : 0.0;
+#pragma unroll
+        for (int s = 0; s < B; ++s) {
+            if (s < nb) {   // wave-uniform
+                const double nv = soft_threshold(fma(b_f, ia_f, old_f), thr_f);
+                const double h_s = readlane_f64(nv - old_f, s);
+                b_f = fma(-h_s, gcol[s], b_f);
+            }
+        }
+        v_me = fma(b_f, ia_f, old_f);
+        nv_me = soft_threshold(v_me, thr_f);
+        h_me = nv_me - old_f;
+    } else
 #pragma unroll
     for (int s = 0; s < B; ++s) {
         if (s < nb) {   // wave-uniform
