@@ -361,7 +361,7 @@ template <typename T, int NG> int32_t launch_gram_chunk(cdh_handle h, int m) {
         } else {
             go(k_gramstep<T, NG, false>);
         }
-        hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + 3) / 4), dim3(256), 0, h->stream, h->d_partials, G, R::N, h->d_red);  // one value per wave
+        hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + kReduceVals - 1) / kReduceVals), dim3(64 * kReduceWaves), 0, h->stream, h->d_partials, G, R::N, h->d_red);
         CHK(allreduce(h, h->d_red, R::N));
         hipLaunchKernelGGL((k_gram_scalar<NG>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb, h->chunk_dup ? 1 : 0, h->d_ctrl,
                            h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos0);
@@ -1065,7 +1065,7 @@ static int32_t cdh_gram_impl(cdh_handle h, int64_t m, const int64_t* idx1, doubl
                            h->d_partials);
         return CDH_OK;
     }));
-    hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + 3) / 4), dim3(256), 0, h->stream, h->d_partials, G, R::N, h->d_red);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + kReduceVals - 1) / kReduceVals), dim3(64 * kReduceWaves), 0, h->stream, h->d_partials, G, R::N, h->d_red);
     HIPCHK(h, hipGetLastError());
     CHK(allreduce(h, h->d_red, R::N));
     std::vector<double> rec((size_t)R::N);

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
     }
 
     if constexpr (LT) __syncthreads();   // every wave is done with its operand tile before s_red aliases it
-    // ---- per-wave record -> LDS -> sum over the block's waves -> value-major partials, one tile
+    // ---- per-wave record -> LDS -> sum over the block's waves -> block-major partials, one tile
     // at a time (an 8 KB staging buffer instead of the whole record x 4 waves) --------------------
     qacc = wave_sum(qacc);
 #pragma unroll
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
             double sum = 0.0;
 #pragma unroll
             for (int wv = 0; wv < kGramWaves; ++wv) sum += s_red[wv][v];
-            partials[(int64_t)(t * 256 + v) * gridDim.x + blockIdx.x] = sum;
+            partials[(int64_t)blockIdx.x * R::N + t * 256 + v] = sum;   // block-major: 2 KB runs
         }
         __syncthreads();
     }
@@ -374,18 +374,42 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
 #pragma unroll
             for (int wv = 0; wv < kGramWaves; ++wv) sum += s_q[wv];
         }
-        partials[(int64_t)(R::OFF_C + v) * gridDim.x + blockIdx.x] = sum;
+        partials[(int64_t)blockIdx.x * R::N + R::OFF_C + v] = sum;
     }
 }
 
-// Stage 1 of the reduction: wave (block*4 + w) sums the runs of values v, v + nwaves, ...
-__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ partials, int nparts,
-                                                     int nvals, double* __restrict__ rec) {
-    const int lane = threadIdx.x & 63;
-    const int nw = gridDim.x * 4;
-    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nvals; v += nw) {
-        const double s = wave_sum_run(partials + (int64_t)v * nparts, nparts, lane);
-        if (lane == 0) rec[v] = s;
+// Stage 1 of the reduction over block-major partials (record b at partials + b * nvals: the
+// streaming kernel stores whole 2 KB runs, where value-major stores were one 8-byte store per line and
+// cost ~9 us of a 234 us launch).  A block of 16 waves owns 32 consecutive values: half-wave lane =
+// value, the 32 half-waves split the records -- group g sums records g, g + 32, ... in that order
+// (256-byte loads, 8 in flight) -- and the 32 group sums are added in group order: a fixed order, so
+// the result is bit-reproducible.
+constexpr int kReduceWaves = 16, kReduceVals = 32, kReduceGroups = 2 * kReduceWaves;
+__global__ __launch_bounds__(64 * kReduceWaves) void k_gram_reduce(const double* __restrict__ partials,
+                                                                   int nparts, int nvals,
+                                                                   double* __restrict__ rec) {
+    __shared__ double s_part[kReduceGroups][kReduceVals];
+    const int lv = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int v = blockIdx.x * kReduceVals + lv;
+    double acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+    if (v < nvals) {
+        const double* col = partials + v;
+        int b = grp;
+        for (; b + 7 * kReduceGroups < nparts; b += 8 * kReduceGroups) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += col[(int64_t)(b + u * kReduceGroups) * nvals];
+        }
+        for (; b < nparts; b += kReduceGroups) acc[0] += col[(int64_t)b * nvals];
+    }
+    s_part[grp][lv] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (threadIdx.x < kReduceVals && v < nvals) {
+        double sum = 0.0;
+#pragma unroll
+        for (int gi = 0; gi < kReduceGroups; ++gi) sum += s_part[gi][lv];
+        rec[v] = sum;
     }
 }
 
