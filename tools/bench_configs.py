@@ -43,7 +43,7 @@ def cfg3(n=2_000_000, p=5000, nlam=100):
 
 def cfg4_shard(n=5_000_000, p=1000):
     f, _ = cd.CDSqrtLassoLoss.generate(n, p, seed=123, s=100, noise=1.0)
-    f.set_sweep_mode("block", 16)
+    f.set_sweep_mode("block", int(os.environ.get("CFG_BLOCK", "16")))
     x = cd.SparseIterate(p)
     t0 = time.perf_counter()
     cd.coordinateDescent_(x, f, cd.ProxL1(4.4612 * np.sqrt(1.0)), cd.CDOptions(optTol=1e-8, randomize=False))
@@ -56,7 +56,7 @@ def cfg4_shard(n=5_000_000, p=1000):
 
 def cfg5_shard(n=10_000_000, p=2000):
     f, _ = cd.CDLeastSquaresLoss.generate(n, p, seed=123, s=100, noise=6.0, dtype=np.float32)
-    f.set_sweep_mode("block", 16)
+    f.set_sweep_mode("block", int(os.environ.get("CFG_BLOCK", "16")))
     om = cd.stdX(f)
     x = cd.SparseIterate(p)
     lam = float(np.sqrt(2 * np.log(p) / n))
