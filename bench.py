@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default=os.environ.get("CDH_BENCH_MODE", "block"), choices=["coord", "block"])
     ap.add_argument("--block", type=int, default=None, choices=[2, 4, 8, 16, 32, 64],
-                    help="visits per launch of the blocked sweep (default 32 on one GPU, 64 sharded: "
+                    help="visits per launch of the blocked sweep (default 32; 64 for row shards under 4e6 rows: "
                          "half the exchanges per sweep)")
     ap.add_argument("--graph", action="store_true", help="replay each pass from a captured hipGraph")
     ap.add_argument("--lam-frac", type=float, default=1e-6, help="lambda / lambda_max")
@@ -148,8 +148,10 @@ def main():
     if cp.world > 1 and a.exchange == "p2p" and sharded.connect_p2p(f, cp):
         exchange = "p2p"
     if a.block is None:
-        # fp32 B = 64 has no LDS-transposed variant (it would spill) and runs far below B = 32
-        a.block = 32 if (cp.world == 1 or a.dtype == "f32") else 64
+        # B = 32 streams fastest per visit on long shards (measured 13.0 vs 13.8 us per visit at 5e6 rows);
+        # from 2.5e6 rows down the two widths tie and B = 64 halves the exchanges.  fp32 B = 64 has no
+        # LDS-transposed variant (it would spill) and runs far below B = 32.
+        a.block = 32 if (cp.world == 1 or a.dtype == "f32" or n_local >= 4_000_000) else 64
     f.set_sweep_mode(a.mode, a.block)
     f.set_use_graph(a.graph)
     x = cd.SparseIterate(a.cols)
