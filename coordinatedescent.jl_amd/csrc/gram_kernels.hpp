@@ -1,4 +1,4 @@
-// gram_kernels.hpp -- wide-block (B = 16 or 32 visits per launch) variant of the blocked sweep.
+// gram_kernels.hpp -- wide-block (B = 16, 32 or 64 visits per launch) variant of the blocked sweep.
 //
 // Same arithmetic as k_blockstep (kernels.hpp): one pass over r applies the previous block's
 // rank-B residual update (cd_differentiable_function.jl:107-109 for B visits) and accumulates
