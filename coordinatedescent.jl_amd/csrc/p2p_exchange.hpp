@@ -24,7 +24,7 @@ constexpr int kP2PMaxRanks = 8;
 constexpr int kP2PMaxCount = 2688;                 // >= the widest block record (2625 doubles)
 constexpr int kP2PWords = 2 * kP2PMaxCount;        // 8-byte words per (slot, source)
 constexpr size_t kP2PInboxBytes = (size_t)2 * kP2PMaxRanks * kP2PWords * sizeof(unsigned long long);
-constexpr unsigned kP2PSpinLimit = 20u * 1000u * 1000u;  // default bound, roughly half a minute
+constexpr unsigned kP2PSpinLimit = 2u * 1000u * 1000u;  // default bound: a few seconds (ranks run in lockstep; env CDH_P2P_SPIN_LIMIT)
 
 struct P2PPeers { unsigned long long* inbox[kP2PMaxRanks]; };
 
