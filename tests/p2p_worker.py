@@ -54,6 +54,20 @@ def main():
         assert np.array_equal(f.exchange_probe(v), 3.0 * np.arange(4096, dtype=np.float64))
         cp.barrier()
         del f
+    # a peer that never arrives: the wait is bounded, the call fails, and a shard whose only exchange
+    # is gone refuses to continue (no silent unsharded arithmetic)
+    os.environ["CDH_P2P_SPIN_LIMIT"] = "200000"
+    f = cd.CDLeastSquaresLoss(y[row0:row0 + nl], X[row0:row0 + nl], device=0, n_total=n, row_offset=row0)
+    assert sharded.connect_p2p(f, cp, selftest=True)
+    if cp.rank == 0:
+        for attempt in range(2):
+            try:
+                f.exchange_probe(np.ones(8))
+                raise AssertionError("a lone rank's exchange must time out")
+            except cd._lib.HipError as e:
+                assert ("timed out" if attempt == 0 else "lost its only exchange") in str(e), str(e)
+    cp.barrier()
+    del f
     if cp.rank == 0:
         print("P2P_OK")
     cp.shutdown()
