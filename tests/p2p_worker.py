@@ -54,6 +54,22 @@ def main():
         assert np.array_equal(f.exchange_probe(v), 3.0 * np.arange(4096, dtype=np.float64))
         cp.barrier()
         del f
+    # sqrt-lasso with penalty weights on shards (the exchange then carries q = r'r as well)
+    om = 0.5 + rng.random(p)
+    xo = oracle.SparseIterate(p)
+    fo2 = oracle.CDSqrtLassoLoss(y, X)
+    oracle.coordinateDescent_(xo, fo2, oracle.ProxL1(3.8, om), oracle.CDOptions(randomize=False, optTol=1e-11, maxIter=500))
+    for block in (0, 32):
+        f = cd.CDSqrtLassoLoss(y[row0:row0 + nl], X[row0:row0 + nl], device=0, n_total=n, row_offset=row0)
+        assert sharded.connect_p2p(f, cp, selftest=False)
+        f.set_sweep_mode("block" if block else "coord", block or 8)
+        x = cd.SparseIterate(p)
+        cd.coordinateDescent_(x, f, cd.ProxL1(3.8, om), opt)
+        err = float(np.max(np.abs(x.dense() - xo.dense())))
+        assert err < 1e-10, ("sqrt", block, err)
+        assert abs(cd.objective(f) - oracle.objective(fo2, oracle.ProxL1(3.8, om), xo)) <= 1e-12 * abs(cd.objective(f))
+        cp.barrier()
+        del f
     # a peer that never arrives: the wait is bounded, the call fails, and a shard whose only exchange
     # is gone refuses to continue (no silent unsharded arithmetic)
     os.environ["CDH_P2P_SPIN_LIMIT"] = "200000"
