@@ -279,7 +279,7 @@ class _HipLoss(CoordinateDifferentiableFunction):
         return out
 
     # -- execution control -----------------------------------------------------------------
-    def set_sweep_mode(self, mode, block=8):
+    def set_sweep_mode(self, mode, block=32):
         mode = {"coord": CDH_SWEEP_COORD, "block": CDH_SWEEP_BLOCK}.get(mode, mode)
         check(self._L.cdh_set_sweep_mode(self._h, int(mode), int(block)), self._h)
 

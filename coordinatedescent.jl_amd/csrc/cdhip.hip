@@ -96,7 +96,7 @@ struct cdh_handle_s {
     bool has_omega = false, has_w = false, y_set = false;
     std::vector<double> h_omega;  // host copy of the penalty weights (thresholds, objective)
     cdh::SupportList x;
-    int mode = CDH_SWEEP_COORD, blockB = 8;
+    int mode = CDH_SWEEP_BLOCK, blockB = 32;   // the fastest width on one GPU; cdh_set_sweep_mode changes it
     bool use_graph = false;
     bool screening = true;        // solves screen their full passes over sparse iterates
     bool reuse_residual = false;  // warm starts skip initialize! when r is known to match beta

@@ -64,7 +64,8 @@ typedef enum cdh_loss { CDH_LS = 0, CDH_SQRT = 1, CDH_WLS = 2 } cdh_loss;
  *                    same iterates), then one rank-B residual update.  One
  *                    all-reduce per block.  B in {2, 4, 8, 16, 32, 64}; with
  *                    observation weights (CDH_WLS) B >= 16, narrower widths then
- *                    run the per-coordinate sweep. */
+ *                    run the per-coordinate sweep.
+ * A new handle sweeps in blocks of B = 32, the fastest width on one GPU. */
 typedef enum cdh_sweep_mode { CDH_SWEEP_COORD = 0, CDH_SWEEP_BLOCK = 1 } cdh_sweep_mode;
 
 /* CDOptions (utils.jl:7-20), field for field, + the seed of the substitute RNG
@@ -175,6 +176,7 @@ int32_t cdh_resid_moments(cdh_handle h, double *out_sum, double *out_sumsq);
 int32_t cdh_objective(cdh_handle h, double *out);
 
 /* ---- execution control (no reference counterpart) ------------------------------- */
+/* default: CDH_SWEEP_BLOCK, block = 32; `block` is ignored for CDH_SWEEP_COORD */
 int32_t cdh_set_sweep_mode(cdh_handle h, int32_t mode, int32_t block);
 /* Warm starts normally rebuild r = y - X beta as the reference's initialize! does
  * (coordinate_descent.jl:21).  With reuse on, a warm start whose iterate is the one the

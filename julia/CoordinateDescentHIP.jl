@@ -150,7 +150,7 @@ end
 
 # Optional knobs (no reference counterpart): blocked sweep width, screened full passes, reuse of
 # the carried residual by warm starts (what LassoPath wants: src/lasso.jl:250-252).
-set_sweep_mode!(X::HipMatrix, blocked::Bool, block::Integer=16) =
+set_sweep_mode!(X::HipMatrix, blocked::Bool, block::Integer=32) =
   check(X.handle, ccall((:cdh_set_sweep_mode, libcdhip), Int32, (Ptr{Cvoid}, Int32, Int32), X.handle, blocked ? 1 : 0, block))
 set_screening!(X::HipMatrix, on::Bool) =
   check(X.handle, ccall((:cdh_set_screening, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, on ? 1 : 0))
