@@ -693,3 +693,42 @@ def test_orthogonal_design_closed_form(mode):
     cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(optTol=1e-13, randomize=True, seed=2))
     np.testing.assert_allclose(x.dense(), want, rtol=0, atol=1e-12)
     assert f.last_stats["passes"] == 3 and f.last_stats["full_passes"] == 2   # full, active, full
+
+
+# ---- randomized shapes / losses / penalties / sweep modes against the oracle ---------------------
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CDH_FUZZ", "24"))))
+def test_random_configurations_match_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    p = int(rng.integers(1, 140))
+    n = int(rng.integers(max(30, 2 * p), 3000))      # n >= 2p: a unique minimiser, as in the reference's tests
+    s = int(rng.integers(0, min(p, 10) + 1))
+    X = np.asfortranarray(rng.standard_normal((n, p)) * rng.uniform(0.2, 3.0, size=p))   # uneven column scales
+    Y = X[:, :s] @ rng.standard_normal(s) + rng.uniform(0.1, 2.0) * rng.standard_normal(n)
+    loss = ["ls", "sqrt", "wls"][seed % 3]
+    mode = MODES[int(rng.integers(0, len(MODES)))]
+    weighted = bool(rng.integers(0, 2))
+    randomize = bool(rng.integers(0, 2))
+    om = rng.uniform(0.5, 2.0, size=p) if weighted else None
+    o = dict(maxIter=3000, optTol=1e-12, randomize=randomize, seed=int(rng.integers(1, 1 << 30)))
+    if loss == "ls":
+        f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+        lam = float(rng.uniform(0.02, 0.6)) * float(np.max(np.abs(X.T @ Y)) / n)
+    elif loss == "wls":
+        w = rng.uniform(0.2, 2.0, size=n)
+        f, fo = cd.CDWeightedLSLoss(Y, X, w), O.CDWeightedLSLoss(Y, X, w)
+        lam = float(rng.uniform(0.02, 0.6)) * float(np.max(np.abs(X.T @ (w * Y))) / n)
+    else:
+        f, fo = cd.CDSqrtLassoLoss(Y, X), O.CDSqrtLassoLoss(Y, X)
+        lam = float(rng.uniform(0.3, 0.9)) * float(np.max(np.abs(X.T @ Y)) / np.linalg.norm(Y))
+        lam = min(lam, 0.5 * float(np.sqrt(np.min(np.sum(X * X, axis=0)))))   # lambda^2 < xsqr (:280-282)
+    _set_mode(f, mode)
+    g, go = (cd.ProxL1(lam, om), O.ProxL1(lam, om)) if weighted else (cd.ProxL1(lam), O.ProxL1(lam))
+    x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+    cd.coordinateDescent_(x, f, g, cd.CDOptions(**o))
+    st = O.coordinateDescent_(xo, fo, go, O.CDOptions(**o))
+    if not st["converged"]:
+        pytest.skip("oracle did not converge at this draw")
+    scale = max(1.0, float(np.max(np.abs(xo.dense()))))
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL * scale,
+                               err_msg=f"n={n} p={p} loss={loss} mode={mode} weighted={weighted} randomize={randomize}")
+    np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-8 * max(1.0, float(np.max(np.abs(Y)))))
