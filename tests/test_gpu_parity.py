@@ -732,3 +732,36 @@ def test_random_configurations_match_oracle(seed):
     np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL * scale,
                                err_msg=f"n={n} p={p} loss={loss} mode={mode} weighted={weighted} randomize={randomize}")
     np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-8 * max(1.0, float(np.max(np.abs(Y)))))
+
+
+# ---- long columns: the variants the library picks by shard length (B = 16 transposed loads from 2e6
+# rows, 64-vector chunks from 16 rounds per launch) at parity level, not only in the timing tools ------
+_LONG = {}
+
+
+def _long_problem():
+    if not _LONG:
+        n, p, s = 4_300_003, 24, 4
+        f, _ = cd.CDLeastSquaresLoss.generate(n, p, seed=7, s=s, noise=2.0)
+        X, Y = f.X_cols(0, p), f.y
+        x = cd.SparseIterate(p)
+        cd.initialize_(f, x)
+        lam = 0.02 * cd.findLambdaMax(x, f, cd.ProxL1(1.0))
+        o = dict(maxIter=200, optTol=1e-12, randomize=False)
+        xo = O.SparseIterate(p)
+        fo = O.CDLeastSquaresLoss(Y, X)
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        _LONG.update(f=f, lam=lam, o=o, want=xo.dense().copy(), obj=O.objective(fo, O.ProxL1(lam), xo), passes=st["passes"])
+    return _LONG
+
+
+@pytest.mark.parametrize("block", [16, 32, 64])
+def test_long_column_variants_match_oracle(block):
+    L = _long_problem()
+    f = L["f"]
+    f.set_sweep_mode("block", block)
+    x = cd.SparseIterate(24)
+    cd.coordinateDescent_(x, f, cd.ProxL1(L["lam"]), cd.CDOptions(**L["o"]))
+    np.testing.assert_allclose(x.dense(), L["want"], rtol=0, atol=BETA_TOL)
+    np.testing.assert_allclose(cd.objective(f), L["obj"], rtol=1e-12)
+    assert f.last_stats["passes"] == L["passes"]
