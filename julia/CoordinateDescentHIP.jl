@@ -111,10 +111,10 @@ function pull_iterate!(f::HipLoss{T}, x::SparseIterate{T}) where {T}
 end
 
 function set_penalty!(f::HipLoss, g::ProxL1)
-  om = g.λ === nothing ? C_NULL : pointer(Float64.(g.λ))
-  n_om = g.λ === nothing ? 0 : length(g.λ)
-  check(f.X.handle, ccall((:cdh_set_penalty, libcdhip), Int32, (Ptr{Cvoid}, Float64, Ptr{Float64}, Int64),
-                          f.X.handle, Float64(g.λ0), om, n_om))
+  om = g.λ === nothing ? Float64[] : Vector{Float64}(g.λ)    # kept alive across the call
+  GC.@preserve om check(f.X.handle,
+    ccall((:cdh_set_penalty, libcdhip), Int32, (Ptr{Cvoid}, Float64, Ptr{Float64}, Int64),
+          f.X.handle, Float64(g.λ0), g.λ === nothing ? Ptr{Float64}(C_NULL) : pointer(om), length(om)))
 end
 
 # ---- the four-function operator interface (src/cd_differentiable_function.jl:1-35) ----------
