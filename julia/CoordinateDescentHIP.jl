@@ -90,10 +90,14 @@ numCoordinates(f::HipLoss) = f.X.p
 function push_iterate!(f::HipLoss, x::SparseIterate, rebuild::Bool)
   idx = Int64.(x.nzval2ind[1:nnz(x)])
   val = Float64.(x.nzval[1:nnz(x)])
-  fn = rebuild ? :cdh_initialize : :cdh_set_iterate
-  GC.@preserve idx val check(f.X.handle,
-    ccall((fn, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
-          f.X.handle, length(x), length(idx), idx, val))
+  GC.@preserve idx val begin          # ccall needs a constant symbol: one call site per entry point
+    st = rebuild ?
+      ccall((:cdh_initialize, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
+            f.X.handle, length(x), length(idx), idx, val) :
+      ccall((:cdh_set_iterate, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
+            f.X.handle, length(x), length(idx), idx, val)
+    check(f.X.handle, st)
+  end
 end
 
 function pull_iterate!(f::HipLoss{T}, x::SparseIterate{T}) where {T}
