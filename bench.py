@@ -158,7 +158,7 @@ def main():
     cd.initialize_(f, x)
     lmax = cd.findLambdaMax(x, f, cd.ProxL1(1.0))
     g = cd.ProxL1(a.lam_frac * lmax)
-    visit = list(range(1, a.cols + 1))
+    visit = np.arange(1, a.cols + 1, dtype=np.int64)
 
     def step():
         # one step = initialize!(f, 0) (beta = 0, r = y) + one full cyclic pass from there:

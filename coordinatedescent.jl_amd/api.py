@@ -486,7 +486,10 @@ def cdPass_(x, f, g, visit):
     visit list; returns maxH."""
     f._set_penalty(g)
     f._ensure_synced(x)
-    idx = np.ascontiguousarray(list(visit), dtype=np.int64)
+    if isinstance(visit, np.ndarray) and visit.dtype == np.int64 and visit.flags.c_contiguous:
+        idx = visit                      # a prepared list crosses as is (sweep loops reuse one)
+    else:
+        idx = np.ascontiguousarray(list(visit), dtype=np.int64)
     out = C.c_double()
     check(f._L.cdh_pass(f._h, idx.shape[0], _vp(idx), C.byref(out)), f._h)
     f._pull(x)

@@ -258,6 +258,12 @@ int32_t resid_moments_dev(cdh_handle h) {  // -> d_red[0..2] = sum r, sum r^2, s
 // ---- initialize!: upload support, r = y - X beta ------------------------------------
 int32_t rebuild_residual(cdh_handle h) {
     const int64_t nnz = h->x.nnz();
+    if (nnz == 0) {   // the cold start: beta = 0, r = y; nothing host-side is in flight, so no wait either
+        HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->r, h->y, (size_t)h->ld * h->esz, hipMemcpyDeviceToDevice, h->stream));
+        h->r_consistent = true;
+        return CDH_OK;
+    }
     std::vector<double> dense((size_t)h->p, 0.0);
     for (int64_t s = 0; s < nnz; ++s) dense[(size_t)h->x.coord(s)] = h->x.slot_value(s);
     HIPCHK(h, hipMemcpyAsync(h->beta, dense.data(), sizeof(double) * h->p, hipMemcpyHostToDevice, h->stream));
@@ -893,6 +899,10 @@ static int32_t cdh_set_iterate_impl(cdh_handle h, int64_t x_length, int64_t nnz,
         // a stored zero keeps its slot in the reference's SparseIterate; mirror that
         if (val[i] == 0.0) { h->x.set(idx1[i] - 1, 1.0); h->x.set(idx1[i] - 1, 0.0); }
         else h->x.set(idx1[i] - 1, val[i]);
+    }
+    if (h->x.nnz() == 0) {   // beta = 0: nothing to upload, nothing to wait for
+        HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
+        return CDH_OK;
     }
     std::vector<double> dense((size_t)h->p, 0.0);
     for (int64_t s = 0; s < h->x.nnz(); ++s) dense[(size_t)h->x.coord(s)] = h->x.slot_value(s);
