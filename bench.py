@@ -96,6 +96,14 @@ def cpu_baseline(f, n, lam, visits_target_s=12.0):
     return out
 
 
+def adopt_direct_exchange(mode, selftest_ok, all_ranks_completed, max_abs_dbeta, t_direct, t_rccl):
+    """--exchange auto: the direct exchange's timing becomes `value` only if it validated in this very
+    run (self-test on every rank, every rank completed the K steps, beta within 1e-9 of the RCCL
+    sweep) AND was faster than RCCL."""
+    return bool(mode == "auto" and selftest_ok and all_ranks_completed and max_abs_dbeta <= 1e-9
+                and 0.0 < t_direct < t_rccl)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,14 +122,15 @@ def main():
     ap.add_argument("--lam-frac", type=float, default=1e-6, help="lambda / lambda_max")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the secondary sparse-regime timing")
-    ap.add_argument("--exchange", default=os.environ.get("CDH_EXCHANGE", "rccl"), choices=["rccl", "p2p"],
-                    help="exchange of the timed region when sharded (p2p: opt-in direct exchange, falls back "
-                         "to rccl if its self-test fails)")
+    ap.add_argument("--exchange", default=os.environ.get("CDH_EXCHANGE", "auto"), choices=["auto", "rccl", "p2p"],
+                    help="exchange when sharded.  auto: time K steps over RCCL, then K steps over the direct "
+                         "exchange if it validates, report the faster (the other goes to exchange_trial); "
+                         "rccl / p2p: that exchange only in the timed region")
     ap.add_argument("--no-rccl", action="store_true",
                     help="TEST ONLY (ranks sharing one GPU, which RCCL refuses): build no communicator; with "
                          "--exchange rccl the timed region then has NO exchange and its numbers mean nothing")
     ap.add_argument("--no-exchange-trial", action="store_true",
-                    help="sharded runs: skip the untimed trial of the other exchange after the timed region")
+                    help="sharded runs: time RCCL only (no second region with the direct exchange)")
     a = ap.parse_args()
 
     import numpy as np
@@ -203,12 +212,14 @@ def main():
         sparse = {"lambda_over_lambda_max": 0.5, "ms_per_sweep": dts / nsp * 1e3,
                   "coord_updates_per_sec": nsp * a.cols / dts, "nnz": int(x.nnz)}
 
-    # sharded runs, outside the timed region: a guarded trial of the opt-in direct exchange (never part
-    # of `value`).  Local failures are caught; the only control-plane collectives are the ones every
-    # rank reaches (connect_p2p's and the two reductions below).
+    # sharded runs: after the RCCL-timed region, the same K steps with the direct exchange
+    # (csrc/p2p_exchange.hpp), guarded.  --exchange auto reports whichever exchange was faster, and the
+    # direct one only if its self-test passed, every rank completed, and beta agrees with the RCCL
+    # sweep to 1e-9; the other timing goes to `exchange_trial`.  Local failures are caught, and every
+    # control-plane collective below is reached by every rank whatever failed locally.
     trial = None
     if cp.world > 1 and exchange != "p2p" and not a.no_exchange_trial:
-        trial, t_loc, ok_loc, err_loc = {"exchange": "p2p"}, 0.0, False, 0.0
+        trial, t_loc, ok_loc, err_loc, prof = {"exchange": "p2p"}, 0.0, False, 1e300, None
         try:
             connected = sharded.connect_p2p(f, cp)
         except Exception as e:          # pragma: no cover - connect_p2p is written not to raise
@@ -218,25 +229,39 @@ def main():
             try:
                 step()
                 L.cdh_synchronize(f._h)
+            except Exception as e:
+                trial["error"] = str(e)[:200]
+        cp.barrier()
+        if connected and "error" not in trial:
+            try:
+                f.profile_begin()
                 tt = time.perf_counter()
                 for _ in range(a.steps):
-                    step()
+                    maxh_p2p = step()
                 L.cdh_synchronize(f._h)
                 t_loc = time.perf_counter() - tt
+                prof = f.profile_end()
                 err_loc = float(np.max(np.abs(x.dense() - beta_timed)))
                 ok_loc = True
             except Exception as e:
                 trial["error"] = str(e)[:200]
-            try:
-                f.p2p_enable(False)
-            except Exception:
-                pass
+        cp.barrier()
         all_ok = cp.sum_over_ranks(1.0 if ok_loc else 0.0) == cp.world
         t_max = cp.max_over_ranks(t_loc)
+        err_max = cp.max_over_ranks(err_loc)
         if connected:
             trial.update({"completed_on_all_ranks": bool(all_ok),
                           "ms_per_step": t_max / a.steps * 1e3 if all_ok else None,
-                          "max_abs_dbeta_vs_rccl": err_loc if ok_loc else None})
+                          "max_abs_dbeta_vs_rccl": err_max if all_ok else None})
+        if adopt_direct_exchange(a.exchange, connected, all_ok, err_max, t_max, dt):
+            trial = {"exchange": "rccl", "ms_per_step": dt / a.steps * 1e3, "p2p_selftest": True,
+                     "max_abs_dbeta_p2p_vs_rccl": err_max}
+            exchange, dt, maxh = "p2p", t_max, maxh_p2p
+            ev_ms, launches, alg_bytes = prof
+        try:
+            f.p2p_enable(False)
+        except Exception:
+            pass
 
     updates = a.steps * a.cols
     value = updates / dt

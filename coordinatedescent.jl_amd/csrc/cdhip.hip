@@ -178,7 +178,8 @@ int32_t upload_ctrl(cdh_handle h) {
 inline bool sharded(const cdh_handle_s* h) { return h->comm != nullptr || h->p2p_on; }
 
 int32_t p2p_check(cdh_handle h) {
-    // reported once, by the call that hit it; the handle then continues without the direct exchange
+    // after a timeout the ranks no longer agree on what has been exchanged: the handle refuses every
+    // later exchange (falling back to RCCL here could pair mismatched all-reduces and hang)
     if (h->p2p_on && *(volatile int*)h->p2p_timeout) {
         h->p2p_on = false;
         h->p2p_dead = true;
@@ -200,10 +201,8 @@ int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
         HIPCHK(h, hipGetLastError());
         return CDH_OK;
     }
-    if (!h->comm) {
-        if (h->p2p_dead) return fail(h, CDH_RCCL_ERROR, "the shard lost its only exchange (p2p timed out, no communicator)");
-        return CDH_OK;
-    }
+    if (h->p2p_dead) return fail(h, CDH_RCCL_ERROR, "the shard lost its exchange (p2p timed out earlier); rebuild the handle");
+    if (!h->comm) return CDH_OK;
     int rc = g_rccl.AllReduce(dbuf, dbuf, count, kNcclDouble, kNcclSum, h->comm, h->stream);
     if (rc != 0) {
         h->err = std::string("ncclAllReduce failed: ") +

@@ -112,8 +112,9 @@ def connect_p2p(loss, cp: ControlPlane, selftest: bool = True) -> bool:
     """OPT-IN direct exchange for the short per-block records (csrc/p2p_exchange.hpp): each
     rank's inbox is IPC-mapped into every peer, handles travel over the control plane.  With
     `selftest`, probe records are exchanged and compared with the exact expected sums on every
-    rank; the exchange is enabled only if EVERY stage succeeded on ALL ranks (else the handle
-    stays on RCCL and False is returned).  Collective: every rank must call it, and every rank
+    rank; the exchange is enabled only if EVERY stage succeeded on ALL ranks (else False is
+    returned and the handle stays on RCCL -- unless the self-test ended in a timeout, after which
+    the library refuses further exchanges on this handle: the ranks may no longer be in step).  Collective: every rank must call it, and every rank
     goes through the same sequence of control-plane collectives whatever fails locally."""
     import numpy as np
     if cp.world == 1:

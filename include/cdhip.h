@@ -201,8 +201,8 @@ int32_t cdh_comm_init(cdh_handle h, const void *id_128_bytes, int32_t rank, int3
  *   1. every rank: cdh_p2p_local_handle -> 64 opaque bytes (a HIP IPC memory handle);
  *   2. all-gather the handles in rank order (any transport), every rank: cdh_p2p_connect;
  *   3. every rank: cdh_p2p_enable(h, 1)  (collectively: all ranks or none).
- * A peer that never arrives ends the wait after a bounded spin and the next call on the
- * handle returns CDH_RCCL_ERROR.  cdh_exchange_probe all-reduces `count` (<= 4096) host
+ * A peer that never arrives ends the wait after a bounded spin; that call and every later
+ * exchange on the handle return CDH_RCCL_ERROR (the ranks no longer agree on what was exchanged).  cdh_exchange_probe all-reduces `count` (<= 4096) host
  * doubles in place through whatever exchange is active (self-test of the transport). */
 int32_t cdh_p2p_local_handle(cdh_handle h, void *out_64_bytes);
 int32_t cdh_p2p_connect(cdh_handle h, const void *handles_64_bytes_each, int32_t rank, int32_t nranks);

@@ -38,3 +38,18 @@ def test_cpu_baseline_loop_is_the_oracle_visit():
         O.cdPass_(x, f, g, np.arange(1, p + 1))
     np.testing.assert_allclose(beta, x.dense(), rtol=0, atol=1e-14)
     np.testing.assert_allclose(r, f.r, rtol=0, atol=1e-12)
+
+
+def test_direct_exchange_is_adopted_only_when_validated_and_faster():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    adopt = bench.adopt_direct_exchange
+    assert adopt("auto", True, True, 3e-13, 0.040, 0.043)
+    assert not adopt("rccl", True, True, 3e-13, 0.040, 0.043)       # asked for RCCL only
+    assert not adopt("auto", False, True, 3e-13, 0.040, 0.043)      # self-test failed somewhere
+    assert not adopt("auto", True, False, 3e-13, 0.040, 0.043)      # a rank did not complete
+    assert not adopt("auto", True, True, 2e-9, 0.040, 0.043)        # beta differs from the RCCL sweep
+    assert not adopt("auto", True, True, 3e-13, 0.050, 0.043)       # slower
+    assert not adopt("auto", True, True, float("nan"), 0.040, 0.043)
