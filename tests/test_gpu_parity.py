@@ -452,13 +452,14 @@ def test_rccl_path_under_torchrun_matches_plain_run(mode_args):
 # ---- the opt-in direct exchange (csrc/p2p_exchange.hpp): two ranks, both on cuda:0, row shards,
 # IPC-mapped inboxes, no RCCL at all.  This is what a one-GPU box can validate of it: the handle
 # plumbing, epochs / slot reuse, chunking, and the sharded arithmetic end to end against the oracle.
-def test_p2p_exchange_two_ranks_one_gpu():
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_p2p_exchange_two_ranks_one_gpu(ranks):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29950 + (os.getpid() % 40)
+    port = 29950 + (os.getpid() % 40) + ranks
     env = dict(os.environ, CDH_P2P_SPIN_LIMIT="4000000")     # a failure must not take minutes
-    a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(root, "tests", "p2p_worker.py")],
                        capture_output=True, text=True, timeout=420, env=env, cwd=root)
