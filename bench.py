@@ -11,7 +11,9 @@ SURVEY's 1e-3 * lambda_max would leave 90% of the coordinates at zero.)
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME 10M x 1000
 problem with rows sharded across ranks (strong scaling), gradient scalars summed by an
-RCCL all-reduce inside the library.
+RCCL all-reduce inside the library; with the default --exchange auto the same K steps are then
+timed over the opt-in direct exchange and the faster validated one is reported (see
+adopt_direct_exchange and DESIGN.md section 6).
 
 Prints ONE JSON line on rank 0.  `roofline` is computed from HIP events recorded on the
 library's own stream around the sweep kernels; `cpu_baseline` times the CPU oracle's
@@ -26,6 +28,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# dmabuf IPC (what this pool's driver supports) for RCCL and for the IPC-mapped inboxes of the direct
+# exchange; must be in the environment before anything initialises HIP
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
