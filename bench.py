@@ -237,20 +237,24 @@ def main():
             except Exception as e:
                 trial["error"] = str(e)[:200]
         cp.barrier()
+        tt = time.perf_counter()
         if connected and "error" not in trial:
             try:
                 f.profile_begin()
-                tt = time.perf_counter()
                 for _ in range(a.steps):
                     maxh_p2p = step()
                 L.cdh_synchronize(f._h)
-                t_loc = time.perf_counter() - tt
-                prof = f.profile_end()
-                err_loc = float(np.max(np.abs(x.dense() - beta_timed)))
                 ok_loc = True
             except Exception as e:
                 trial["error"] = str(e)[:200]
         cp.barrier()
+        if ok_loc:                      # same bracket as the RCCL region: barrier, K steps, synchronize, barrier
+            t_loc = time.perf_counter() - tt
+            try:
+                prof = f.profile_end()
+                err_loc = float(np.max(np.abs(x.dense() - beta_timed)))
+            except Exception as e:
+                ok_loc, trial["error"] = False, str(e)[:200]
         all_ok = cp.sum_over_ranks(1.0 if ok_loc else 0.0) == cp.world
         t_max = cp.max_over_ranks(t_loc)
         err_max = cp.max_over_ranks(err_loc)
