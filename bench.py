@@ -196,6 +196,11 @@ def main():
     dt = cp.max_over_ranks(time.perf_counter() - t0)
     ev_ms, launches, alg_bytes = f.profile_end()
     beta_timed, moved = x.dense().copy(), int(x.nnz)
+    # the record one exchange carries in this sweep mode (4 doubles per coordinate; c, G, q per block)
+    rec_doubles = {16: 273, 32: 801, 64: 2625}.get(a.block, 4 * a.block) if a.mode == "block" else 4
+    exch_us = {}
+    if cp.world > 1 and exchange != "none(test-only)":
+        exch_us[exchange] = f.exchange_latency(rec_doubles, 200)      # back-to-back all-reduces, HIP events
 
     # secondary, outside the timed region: the "sparse" regime of SURVEY 8d (lambda = 0.5 lambda_max,
     # few coordinates move, a visit is dots only).  Reported for context; never part of `value`.
@@ -256,6 +261,11 @@ def main():
             except Exception as e:
                 ok_loc, trial["error"] = False, str(e)[:200]
         all_ok = cp.sum_over_ranks(1.0 if ok_loc else 0.0) == cp.world
+        if all_ok:
+            try:
+                exch_us["p2p"] = f.exchange_latency(rec_doubles, 200)
+            except Exception as e:
+                trial["error"] = str(e)[:200]
         t_max = cp.max_over_ranks(t_loc)
         err_max = cp.max_over_ranks(err_loc)
         if connected:
@@ -302,6 +312,8 @@ def main():
         res["sparse_regime"] = sparse
     if trial is not None:
         res["exchange_trial"] = trial
+    if exch_us:
+        res["exchange_latency_us"] = dict(exch_us, doubles=rec_doubles, how="200 back-to-back all-reduces, HIP events")
     if cp.rank == 0 and cp.world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(f, n_local, g.lambda0)
         res["cpu_baseline"] = cb[1]

@@ -130,6 +130,7 @@ def lib():
         "cdh_p2p_connect": [vp, vp, i32, i32],
         "cdh_p2p_enable": [vp, i32],
         "cdh_exchange_probe": [vp, vp, i64],
+        "cdh_exchange_latency": [vp, i64, i32, P(f64)],
         "cdh_profile_begin": [vp],
         "cdh_profile_end": [vp, P(f64), P(i64), P(f64)],
     }

@@ -313,6 +313,12 @@ class _HipLoss(CoordinateDifferentiableFunction):
         check(self._L.cdh_exchange_probe(self._h, v.ctypes.data_as(C.c_void_p), v.size), self._h)
         return v
 
+    def exchange_latency(self, count, iters=200):
+        """Average microseconds per all-reduce of `count` doubles through the active exchange (collective)."""
+        out = C.c_double()
+        check(self._L.cdh_exchange_latency(self._h, int(count), int(iters), C.byref(out)), self._h)
+        return out.value
+
     def profile_begin(self):
         check(self._L.cdh_profile_begin(self._h), self._h)
 

@@ -1223,6 +1223,24 @@ int32_t cdh_exchange_probe(cdh_handle h, double* inout, int64_t count) {
     return p2p_check(h);
 }
 
+int32_t cdh_exchange_latency(cdh_handle h, int64_t count, int32_t iters, double* out_us) {
+    if (count < 1 || count > 4096 || iters < 1 || iters > 100000 || !out_us) return fail(h, CDH_BAD_ARG, "latency probe: 1 <= count <= 4096, 1 <= iters <= 100000");
+    if (!h->d_red) return fail(h, CDH_BAD_ARG, "probe: handle has no data yet");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->ev0) { HIPCHK(h, hipEventCreate(&h->ev0)); HIPCHK(h, hipEventCreate(&h->ev1)); }
+    HIPCHK(h, hipMemsetAsync(h->d_red, 0, sizeof(double) * (size_t)count, h->stream));
+    for (int i = 0; i < 3; ++i) CHK(allreduce(h, h->d_red, (size_t)count));   // warm the path
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < iters; ++i) CHK(allreduce(h, h->d_red, (size_t)count));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    CHK(p2p_check(h));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *out_us = (double)ms * 1e3 / iters;
+    return CDH_OK;
+}
+
 int32_t cdh_profile_begin(cdh_handle h) {
     h->prof = true; h->prof_ms = 0.0; h->prof_bytes = 0.0; h->prof_launches = 0;
     return CDH_OK;

@@ -208,6 +208,10 @@ int32_t cdh_p2p_local_handle(cdh_handle h, void *out_64_bytes);
 int32_t cdh_p2p_connect(cdh_handle h, const void *handles_64_bytes_each, int32_t rank, int32_t nranks);
 int32_t cdh_p2p_enable(cdh_handle h, int32_t on);
 int32_t cdh_exchange_probe(cdh_handle h, double *inout, int64_t count);
+/* Average time (microseconds, HIP events on the handle's stream) of `iters` back-to-back all-reduces
+ * of `count` (<= 4096) doubles through the active exchange; 0-ish when the handle is not sharded.
+ * Collective: every rank calls it with the same arguments. */
+int32_t cdh_exchange_latency(cdh_handle h, int64_t count, int32_t iters, double *out_us);
 /* HIP-event timing of the sweep kernels on the handle's stream: everything
  * launched by cdh_pass / cdh_solve between begin and end.  out_launches counts
  * the dominant (column-streaming) kernel launches, out_ms the event time they

@@ -503,6 +503,7 @@ def test_bench_exchange_trial_code_path_two_ranks_one_gpu():
     t = ja["exchange_trial"]
     assert t["selftest"] is True and t["completed_on_all_ranks"] is True and t["ms_per_step"] > 0
     assert "error" not in t
+    assert 0.0 < ja["exchange_latency_us"]["p2p"] < 1e4 and ja["exchange_latency_us"]["doubles"] == 273
 
 
 # ---- section 8(f) rows: screening init kept on the device, LassoPath without the rebuild ---------
