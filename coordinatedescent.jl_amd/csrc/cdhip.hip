@@ -879,8 +879,9 @@ static int32_t cdh_set_penalty_impl(cdh_handle h, double lambda0, const double* 
     }
     h->ctrl.lambda0 = lambda0;
     h->ctrl.has_omega = h->has_omega ? 1 : 0;
-    CHK(upload_ctrl(h));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // the control block goes to the device at the start of every chunk (run_chunk); only the caller's
+    // weight buffer, borrowed for this call, has to be consumed before returning
+    if (omega) HIPCHK(h, hipStreamSynchronize(h->stream));
     return CDH_OK;
 }
 
