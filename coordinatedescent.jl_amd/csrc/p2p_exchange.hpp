@@ -43,20 +43,31 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ buf,
             __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        double sum = 0.0;
-        for (int s = 0; s < nranks; ++s) {   // rank order: the same sum on every rank
-            const unsigned long long* src = peers.inbox[rank] + slot_off + (size_t)s * kP2PWords + 2 * (size_t)v;
-            unsigned long long a = 0, b = 0;
-            unsigned spins = 0;
-            for (;;) {
-                a = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                b = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((unsigned)(a >> 32) == epoch && (unsigned)(b >> 32) == epoch) break;
+        // poll every source at once (one round trip when the data is there: a source-by-source wait
+        // would chain nranks uncached-load latencies), re-reading only the slots still behind
+        const unsigned long long* src0 = peers.inbox[rank] + slot_off + 2 * (size_t)v;
+        unsigned long long a[kP2PMaxRanks] = {}, b[kP2PMaxRanks] = {};
+        unsigned pending = (1u << nranks) - 1u, spins = 0;
+        while (pending) {
+#pragma unroll
+            for (int s = 0; s < kP2PMaxRanks; ++s)
+                if ((pending >> s) & 1u) {
+                    a[s] = __hip_atomic_load(src0 + (size_t)s * kP2PWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    b[s] = __hip_atomic_load(src0 + (size_t)s * kP2PWords + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+#pragma unroll
+            for (int s = 0; s < kP2PMaxRanks; ++s)
+                if (((pending >> s) & 1u) && (unsigned)(a[s] >> 32) == epoch && (unsigned)(b[s] >> 32) == epoch)
+                    pending &= ~(1u << s);
+            if (pending) {
                 if (++spins > limit) { *(volatile int*)timeout_flag = 1; break; }   // never hang the GPU
                 __builtin_amdgcn_s_sleep(8);
             }
-            sum += __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
         }
+        double sum = 0.0;
+#pragma unroll
+        for (int s = 0; s < kP2PMaxRanks; ++s)   // rank order: the same sum on every rank
+            if (s < nranks) sum += __longlong_as_double((long long)((a[s] & 0xffffffffull) | (b[s] << 32)));
         buf[v] = sum;
     }
 }

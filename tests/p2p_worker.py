@@ -52,6 +52,9 @@ def main():
         # longer than one inbox slot and no communicator: chunked through the same inboxes
         v = np.arange(4096, dtype=np.float64) * (1 + cp.rank)
         assert np.array_equal(f.exchange_probe(v), (cp.world * (cp.world + 1) / 2) * np.arange(4096, dtype=np.float64))
+        lat = f.exchange_latency(2625, 100)          # collective; informational
+        if cp.rank == 0:
+            print(f"P2P_LATENCY world={cp.world} mode={mode}{block} us={lat:.1f}")
         cp.barrier()
         del f
     # sqrt-lasso with penalty weights on shards (the exchange then carries q = r'r as well)
