@@ -189,14 +189,20 @@ int32_t p2p_check(cdh_handle h) {
     return CDH_OK;
 }
 
+static_assert(GramRec<4>::N <= cdk::kP2PMaxCount, "the widest block record must fit one inbox slot");
+// the arguments of the next direct exchange (epochs count exchanges; 0 means "never written")
+cdk::P2PCall next_p2p_call(cdh_handle h) {
+    h->p2p_epoch = h->p2p_epoch == 0xffffffffu ? 2u : h->p2p_epoch + 1u;
+    return cdk::P2PCall{h->p2p_peers, h->rank, h->p2p_ranks, h->p2p_epoch, h->p2p_spin_limit, h->p2p_timeout};
+}
+
 int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
     if (h->p2p_on && (count <= (size_t)cdk::kP2PMaxCount || !h->comm)) {
         CHK(p2p_check(h));
         for (size_t o = 0; o < count; o += cdk::kP2PMaxCount) {
             const int c = (int)std::min<size_t>(cdk::kP2PMaxCount, count - o);
-            h->p2p_epoch = h->p2p_epoch == 0xffffffffu ? 2u : h->p2p_epoch + 1u;  // 0 = never written
             hipLaunchKernelGGL(cdk::k_p2p_allreduce, dim3((c + 255) / 256), dim3(256), 0, h->stream, dbuf + o, c,
-                               h->p2p_peers, h->rank, h->p2p_ranks, h->p2p_epoch, h->p2p_spin_limit, h->p2p_timeout);
+                               next_p2p_call(h));
         }
         HIPCHK(h, hipGetLastError());
         return CDH_OK;

@@ -28,48 +28,65 @@ constexpr unsigned kP2PSpinLimit = 2u * 1000u * 1000u;  // default bound: a few 
 
 struct P2PPeers { unsigned long long* inbox[kP2PMaxRanks]; };
 
-__global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ buf, int count, P2PPeers peers,
-                                                       int rank, int nranks, unsigned epoch,
-                                                       unsigned spin_limit, int* timeout_flag) {
-    // an exchange that already timed out poisons the ones queued behind it: they do not wait again
-    const unsigned limit = *(volatile int*)timeout_flag ? 0u : spin_limit;
+// One value through the exchange: store it (epoch-tagged halves) into slot [rank] of every inbox, wait for
+// every source in the own inbox, return the rank-ordered sum.  Called by one thread per value.
+__device__ __forceinline__ double p2p_exchange_value(double mine, int v, const P2PPeers& peers, int rank,
+                                                     int nranks, unsigned epoch, unsigned limit,
+                                                     int* timeout_flag) {
     const size_t slot_off = (size_t)(epoch & 1u) * kP2PMaxRanks * kP2PWords;
-    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < count; v += gridDim.x * blockDim.x) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(buf[v]);
-        const unsigned long long tag = (unsigned long long)epoch << 32;
-        const unsigned long long w0 = tag | (bits & 0xffffffffull), w1 = tag | (bits >> 32);
-        for (int q = 0; q < nranks; ++q) {   // my words into slot [rank] of every inbox (mine included)
-            unsigned long long* dst = peers.inbox[q] + slot_off + (size_t)rank * kP2PWords + 2 * (size_t)v;
-            __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        // poll every source at once (one round trip when the data is there: a source-by-source wait
-        // would chain nranks uncached-load latencies), re-reading only the slots still behind
-        const unsigned long long* src0 = peers.inbox[rank] + slot_off + 2 * (size_t)v;
-        unsigned long long a[kP2PMaxRanks] = {}, b[kP2PMaxRanks] = {};
-        unsigned pending = (1u << nranks) - 1u, spins = 0;
-        while (pending) {
-#pragma unroll
-            for (int s = 0; s < kP2PMaxRanks; ++s)
-                if ((pending >> s) & 1u) {
-                    a[s] = __hip_atomic_load(src0 + (size_t)s * kP2PWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    b[s] = __hip_atomic_load(src0 + (size_t)s * kP2PWords + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-#pragma unroll
-            for (int s = 0; s < kP2PMaxRanks; ++s)
-                if (((pending >> s) & 1u) && (unsigned)(a[s] >> 32) == epoch && (unsigned)(b[s] >> 32) == epoch)
-                    pending &= ~(1u << s);
-            if (pending) {
-                if (++spins > limit) { *(volatile int*)timeout_flag = 1; break; }   // never hang the GPU
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
-        double sum = 0.0;
-#pragma unroll
-        for (int s = 0; s < kP2PMaxRanks; ++s)   // rank order: the same sum on every rank
-            if (s < nranks) sum += __longlong_as_double((long long)((a[s] & 0xffffffffull) | (b[s] << 32)));
-        buf[v] = sum;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+    const unsigned long long tag = (unsigned long long)epoch << 32;
+    const unsigned long long w0 = tag | (bits & 0xffffffffull), w1 = tag | (bits >> 32);
+    for (int q = 0; q < nranks; ++q) {   // my words into slot [rank] of every peer's inbox
+        if (q == rank) continue;         // my own contribution never goes through memory
+        unsigned long long* dst = peers.inbox[q] + slot_off + (size_t)rank * kP2PWords + 2 * (size_t)v;
+        __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // poll every source at once (one round trip when the data is there: a source-by-source wait
+    // would chain nranks uncached-load latencies), re-reading only the slots still behind
+    const unsigned long long* src0 = peers.inbox[rank] + slot_off + 2 * (size_t)v;
+    unsigned long long a[kP2PMaxRanks] = {}, b[kP2PMaxRanks] = {};
+    unsigned pending = ((1u << nranks) - 1u) & ~(1u << rank), spins = 0;
+    while (pending) {
+#pragma unroll
+        for (int s = 0; s < kP2PMaxRanks; ++s)
+            if ((pending >> s) & 1u) {
+                a[s] = __hip_atomic_load(src0 + (size_t)s * kP2PWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                b[s] = __hip_atomic_load(src0 + (size_t)s * kP2PWords + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+#pragma unroll
+        for (int s = 0; s < kP2PMaxRanks; ++s)
+            if (((pending >> s) & 1u) && (unsigned)(a[s] >> 32) == epoch && (unsigned)(b[s] >> 32) == epoch)
+                pending &= ~(1u << s);
+        if (pending) {
+            if (++spins > limit) { *(volatile int*)timeout_flag = 1; break; }   // never hang the GPU
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int s = 0; s < kP2PMaxRanks; ++s)   // rank order: the same sum on every rank
+        if (s < nranks) sum += (s == rank) ? mine : __longlong_as_double((long long)((a[s] & 0xffffffffull) | (b[s] << 32)));
+    return sum;
+}
+
+// what a kernel needs to take part in exchange number `epoch`
+struct P2PCall {
+    P2PPeers peers;
+    int rank, nranks;
+    unsigned epoch, spin_limit;
+    int* timeout_flag;
+};
+// an exchange that already timed out poisons the ones queued behind it: they do not wait again
+__device__ __forceinline__ unsigned p2p_spin_budget(const P2PCall& c) {
+    return *(volatile int*)c.timeout_flag ? 0u : c.spin_limit;
+}
+
+__global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ buf, int count, P2PCall c) {
+    const unsigned limit = p2p_spin_budget(c);
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < count; v += gridDim.x * blockDim.x)
+        buf[v] = p2p_exchange_value(buf[v], v, c.peers, c.rank, c.nranks, c.epoch, limit, c.timeout_flag);
 }
 
 }  // namespace cdk
