@@ -28,6 +28,14 @@ def _problem(seed, n, p, s, noise=1.0):
     return rng, X, Y
 
 
+def _free_port():
+    """A port the OS says is free right now, for torch.distributed.run's rendezvous on 127.0.0.1."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _set_mode(f, mode):
     if mode[0] == "block":
         f.set_sweep_mode("block", mode[1])
@@ -433,7 +441,7 @@ def test_rccl_path_under_torchrun_matches_plain_run(mode_args):
     common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--rows", "300000", "--cols", "96",
               "--planted", "10", "--no-cpu-baseline"] + mode_args
     env = dict(os.environ, CDH_FORCE_RCCL="1")
-    port = 29600 + (os.getpid() % 300)
+    port = _free_port()
     a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(root, "bench.py")] + common,
@@ -457,7 +465,7 @@ def test_p2p_exchange_two_ranks_one_gpu(ranks):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29950 + (os.getpid() % 40) + ranks
+    port = _free_port()
     env = dict(os.environ, CDH_P2P_SPIN_LIMIT="4000000")     # a failure must not take minutes
     a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
@@ -472,7 +480,7 @@ def _bench_two_ranks_one_gpu(extra):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29900 + (os.getpid() % 40)
+    port = _free_port()
     env = dict(os.environ, CDH_P2P_SPIN_LIMIT="4000000")
     cmd = ["--steps", "2", "--warmup", "1", "--rows", "300000", "--cols", "96", "--planted", "10",
            "--no-cpu-baseline", "--no-sparse", "--block", "16"]
