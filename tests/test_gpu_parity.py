@@ -777,3 +777,34 @@ def test_long_column_variants_match_oracle(block):
     np.testing.assert_allclose(x.dense(), L["want"], rtol=0, atol=BETA_TOL)
     np.testing.assert_allclose(cd.objective(f), L["obj"], rtol=1e-12)
     assert f.last_stats["passes"] == L["passes"]
+
+
+# ---- the reference's own benchmark shape (benchmark/cd_bench.jl:8-38): n = 3000, p = 5000 (p > n),
+# s = 100, noise 6; scaledLasso! with lambda = sqrt(2 log p / n) and stdX weights, then plain
+# coordinateDescent! at lambda = 0.001 (thousands of non-zeros; compared after a fixed number of passes,
+# since neither side converges within the reference's own budget there) --------------------------------
+def test_reference_benchmark_shape():
+    rng = np.random.default_rng(123)
+    n, p, s = 3000, 5000, 100
+    X = np.asfortranarray(rng.standard_normal((n, p)))
+    Y = X[:, :s] @ (rng.standard_normal(s) * (1.0 + rng.random(s))) + 6.0 * rng.standard_normal(n)
+    f = cd.CDLeastSquaresLoss(Y, X)
+    sx = cd.stdX(f)
+    np.testing.assert_allclose(sx, np.sqrt((X * X).sum(0) / n), rtol=1e-13)
+    lam = float(np.sqrt(2.0 * np.log(p) / n))
+    x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+    cdo = dict(randomize=False, optTol=1e-9)
+    sol = cd.scaledLasso_(x, f, None, lam, sx, cd.IterLassoOptions(optTol=1e-3, maxIter=50, optionsCD=cd.CDOptions(**cdo)))
+    so = O.scaledLasso_(xo, X, Y, lam, sx, O.IterLassoOptions(optTol=1e-3, maxIter=50, optionsCD=O.CDOptions(**cdo)))
+    np.testing.assert_allclose(sol.sigma, so.sigma, rtol=1e-9)
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-8)
+    assert x.nnz == xo.nnz
+    # coordinateDescent! at lambda = 0.001, warm start from zero, 40 passes on both sides
+    x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+    o = dict(randomize=False, optTol=1e-7, maxIter=40)
+    cd.coordinateDescent_(x, f, cd.ProxL1(0.001), cd.CDOptions(**o))
+    fo = O.CDLeastSquaresLoss(Y, X)
+    st = O.coordinateDescent_(xo, fo, O.ProxL1(0.001), O.CDOptions(**o))
+    assert f.last_stats["passes"] == st["passes"] == 40 and not st["converged"]
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-8)
+    np.testing.assert_allclose(cd.objective(f), O.objective(fo, O.ProxL1(0.001), xo), rtol=1e-10)
