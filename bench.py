@@ -11,11 +11,12 @@ SURVEY's 1e-3 * lambda_max would leave 90% of the coordinates at zero.)
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME 10M x 1000
 problem with rows sharded across ranks (strong scaling), gradient scalars summed by an
-RCCL all-reduce inside the library; with the default --exchange auto the same K steps are then
-timed over the opt-in direct exchange and the faster validated one is reported (see
-adopt_direct_exchange and DESIGN.md section 6).
+RCCL all-reduce inside the library (--exchange rccl, the default: the only exchange in the
+timed region, nothing else runs afterwards).  --exchange auto additionally times the same K
+steps over the opt-in direct exchange AFTER the RCCL result line has been printed and flushed,
+and prints a second line with the faster validated one (adopt_direct_exchange).
 
-Prints ONE JSON line on rank 0.  `roofline` is computed from HIP events recorded on the
+Prints ONE JSON line on rank 0 (two with --exchange auto at N > 1: the RCCL line first).  `roofline` is computed from HIP events recorded on the
 library's own stream around the sweep kernels; `cpu_baseline` times the CPU oracle's
 restatement of the reference visit (kind "port": the reference is Julia, not runnable
 here) on a bounded sample of the same data.
@@ -45,6 +46,11 @@ def profiled_traffic(kernel, rows, cols, dtype, block):
     except Exception:
         return None
     return tab.get(f"{kernel}:n{rows}:p{cols}:{dtype}:B{block}")
+
+
+def esz_of(dtype):
+    import numpy as np
+    return np.dtype(dtype).itemsize
 
 
 def host_threads(omp_max):
@@ -101,6 +107,46 @@ def cpu_baseline(f, n, lam, visits_target_s=12.0):
     return out
 
 
+def cfg1_cpu_vs_gpu(device=0):
+    """BASELINE.json configs[0] run in full on both sides: lasso, n=1000, p=200, s=10,
+    sigma=1, lambda=0.1, host-generated, ordered sweeps, optTol 1e-7 -- the reference's own CPU-runnable
+    case.  CPU = the oracle's C restatement (kind "port", 1 thread); GPU = the same solve through the
+    C ABI, upload excluded (data resident, as for `value`) and included.  At this size one pass is 200
+    visits of 8 KB columns: the GPU side is launch-latency bound, and it is reported as it is."""
+    import numpy as np
+    import coordinatedescent_jl_amd as cd
+    import oracle as O
+    rng = np.random.default_rng(123)
+    n, p, s, lam = 1000, 200, 10, 0.1
+    X = np.asfortranarray(rng.standard_normal((n, p)))
+    y = X[:, :s] @ (rng.standard_normal(s) * (1.0 + rng.random(s))) + rng.standard_normal(n)
+    o = dict(maxIter=2000, optTol=1e-7, randomize=False)
+    reps = 20
+    fo = O.CDLeastSquaresLoss(y, X)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        xo = O.SparseIterate(p)
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+    t_cpu = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    f = cd.CDLeastSquaresLoss(y, X, device=device)
+    t_up = time.perf_counter() - t0
+    xg = cd.SparseIterate(p)
+    cd.coordinateDescent_(xg, f, cd.ProxL1(lam), cd.CDOptions(**o))      # warm the launch path
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        xg = cd.SparseIterate(p)
+        cd.coordinateDescent_(xg, f, cd.ProxL1(lam), cd.CDOptions(**o))
+    t_gpu = (time.perf_counter() - t0) / reps
+    passes, visits = f.last_stats["passes"], f.last_stats["visits"]
+    f.close()
+    return {"workload": "lasso_n1000_p200_s10_lambda0.1_full_solve", "cpu_port_ms": t_cpu * 1e3, "cpu_cores": 1,
+            "gpu_ms": t_gpu * 1e3, "gpu_ms_incl_upload_and_create": (t_gpu + t_up) * 1e3,
+            "passes": passes, "visits": visits, "cpu_passes": st["passes"],
+            "cpu_coord_updates_per_sec": st["visits"] / t_cpu, "gpu_coord_updates_per_sec": visits / t_gpu,
+            "max_abs_beta_diff": float(np.max(np.abs(xg.dense() - xo.dense()))), "tolerance": 1e-10}
+
+
 def adopt_direct_exchange(mode, selftest_ok, all_ranks_completed, max_abs_dbeta, t_direct, t_rccl):
     """--exchange auto: the direct exchange's timing becomes `value` only if it validated in this very
     run (self-test on every rank, every rank completed the K steps, beta within 1e-9 of the RCCL
@@ -127,15 +173,16 @@ def main():
     ap.add_argument("--lam-frac", type=float, default=1e-6, help="lambda / lambda_max")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the secondary sparse-regime timing")
-    ap.add_argument("--exchange", default=os.environ.get("CDH_EXCHANGE", "auto"), choices=["auto", "rccl", "p2p"],
-                    help="exchange when sharded.  auto: time K steps over RCCL, then K steps over the direct "
-                         "exchange if it validates, report the faster (the other goes to exchange_trial); "
-                         "rccl / p2p: that exchange only in the timed region")
+    ap.add_argument("--exchange", default=os.environ.get("CDH_EXCHANGE", "rccl"), choices=["auto", "rccl", "p2p"],
+                    help="exchange when sharded.  rccl (default) / p2p: that exchange only, one result line.  "
+                         "auto: time K steps over RCCL, print that line, then K steps over the direct exchange "
+                         "if it validates and print a second line with the faster (the other in exchange_trial)")
     ap.add_argument("--no-rccl", action="store_true",
                     help="TEST ONLY (ranks sharing one GPU, which RCCL refuses): build no communicator; with "
                          "--exchange rccl the timed region then has NO exchange and its numbers mean nothing")
     ap.add_argument("--no-exchange-trial", action="store_true",
-                    help="sharded runs: time RCCL only (no second region with the direct exchange)")
+                    help="with --exchange auto: skip the second region (same as --exchange rccl)")
+    ap.add_argument("--no-cfg1", action="store_true", help="skip the cfg1 (n=1000, p=200) CPU-vs-GPU solve timing")
     a = ap.parse_args()
 
     import numpy as np
@@ -192,6 +239,7 @@ def main():
     for _ in range(a.steps):
         maxh = step()
     L.cdh_synchronize(f._h)
+    dt_local = time.perf_counter() - t0          # this rank's own K steps (reported as min / max over ranks)
     cp.barrier()
     dt = cp.max_over_ranks(time.perf_counter() - t0)
     ev_ms, launches, alg_bytes = f.profile_end()
@@ -207,6 +255,7 @@ def main():
     sparse = None
     if not a.no_sparse:
         gs = cd.ProxL1(0.5 * lmax)
+        f.set_screening(2)     # cdh_pass may settle runs of non-moving visits from one dots-only pass over their columns
         x.fill_(0.0)
         cd.initialize_(f, x)
         cd.cdPass_(x, f, gs, visit)
@@ -219,17 +268,66 @@ def main():
         L.cdh_synchronize(f._h)
         cp.barrier()
         dts = cp.max_over_ranks(time.perf_counter() - ts)
+        f.set_screening(1)
         sparse = {"lambda_over_lambda_max": 0.5, "ms_per_sweep": dts / nsp * 1e3,
-                  "coord_updates_per_sec": nsp * a.cols / dts, "nnz": int(x.nnz)}
+                  "coord_updates_per_sec": nsp * a.cols / dts, "nnz": int(x.nnz),
+                  "GBps_X_once": esz_of(dtype) * n_local * a.cols * nsp / dts / 1e9, "screened_pass": True}
 
-    # sharded runs: after the RCCL-timed region, the same K steps with the direct exchange
-    # (csrc/p2p_exchange.hpp), guarded.  --exchange auto reports whichever exchange was faster, and the
-    # direct one only if its self-test passed, every rank completed, and beta agrees with the RCCL
-    # sweep to 1e-9; the other timing goes to `exchange_trial`.  Local failures are caught, and every
-    # control-plane collective below is reached by every rank whatever failed locally.
-    trial = None
-    if cp.world > 1 and exchange != "p2p" and not a.no_exchange_trial:
-        trial, t_loc, ok_loc, err_loc, prof = {"exchange": "p2p"}, 0.0, False, 1e300, None
+    esz = np.dtype(dtype).itemsize
+    kernel = ("k_gramstep" if a.block >= 16 else "k_blockstep") if a.mode == "block" else "k_step"
+    dt_loc_min, dt_loc_max = cp.min_over_ranks(dt_local), cp.max_over_ranks(dt_local)
+
+    def result(exchange, dt, maxh, ev_ms, launches, alg_bytes):
+        """The JSON line for a timed region (K steps, max-over-ranks wall time dt, HIP-event time ev_ms)."""
+        updates = a.steps * a.cols
+        achieved = alg_bytes / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else 0.0
+        stream_model = esz * n_local * 5.0 * updates / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else 0.0
+        st = f.exchange_stats()
+        return {
+            "metric": "coord_updates_per_sec", "value": updates / dt, "unit": "coord-updates/s",
+            "n_gpus": cp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"lasso_full_cyclic_sweep_gaussian_n{a.rows}_p{a.cols}_{a.dtype}_allmove",
+                       "n": a.rows, "p": a.cols, "s": a.planted, "noise": a.noise, "lambda_over_lambda_max": a.lam_frac,
+                       "sweep_mode": a.mode + (str(a.block) if a.mode == "block" else ""), "graph": bool(a.graph),
+                       "parallelism": f"rows{cp.world}",
+                       "exchange": exchange if (cp.world > 1 or st["rccl_calls"] > 0) else None,
+                       "moved_per_sweep": moved, "last_maxH": maxh},
+            # what the exchange itself reports: the communicator's rank count (ncclCommCount) and how many
+            # all-reduces went through each transport since the handle was created (rank 0)
+            "exchange_stats": st,
+            "ms_per_step_ranks": {"min": dt_loc_min / a.steps * 1e3, "max": dt_loc_max / a.steps * 1e3},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": profiled_traffic(kernel, n_local, a.cols, a.dtype, a.block if a.mode == "block" else 1),
+                         "traffic_source": "profiles/hbm_traffic.json: rocprofv3 --pmc passes of this exact "
+                                           "configuration (committed), not counters of this run",
+                         "kernel": kernel,
+                         "launches": launches, "avg_launch_us": ev_ms * 1e3 / max(launches, 1),
+                         "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
+                         "stream_model_5n_GBps": stream_model,
+                         "floor_X_once_GBps": esz * n_local * updates / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else 0.0},
+        }
+
+    res = result(exchange, dt, maxh, ev_ms, launches, alg_bytes)
+    if sparse is not None:
+        res["sparse_regime"] = sparse
+    if exch_us:
+        res["exchange_latency_us"] = dict(exch_us, doubles=rec_doubles, how="200 back-to-back all-reduces, HIP events")
+
+    # --exchange auto at N > 1: the RCCL result is on stdout (flushed) BEFORE the direct exchange -- which
+    # has never run across GPUs in this pipeline -- is touched; whatever the trial does, that line stands.
+    run_trial = cp.world > 1 and a.exchange == "auto" and exchange != "p2p" and not a.no_exchange_trial
+    if run_trial and cp.rank == 0:
+        print(json.dumps(res), flush=True)
+    if run_trial and os.environ.get("CDH_BENCH_TRIAL_ABORT"):
+        # TEST ONLY: the worst a trial can do is take the process down (a GPU fault aborts it); the test
+        # checks that the line above has already reached stdout when that happens
+        cp.barrier()
+        os._exit(3)
+    if run_trial:
+        trial, t_loc, ok_loc, err_loc, prof, maxh_p2p = {"exchange": "p2p"}, 0.0, False, 1e300, None, maxh
         try:
             connected = sharded.connect_p2p(f, cp)
         except Exception as e:          # pragma: no cover - connect_p2p is written not to raise
@@ -272,48 +370,24 @@ def main():
             trial.update({"completed_on_all_ranks": bool(all_ok),
                           "ms_per_step": t_max / a.steps * 1e3 if all_ok else None,
                           "max_abs_dbeta_vs_rccl": err_max if all_ok else None})
+        t_min = cp.min_over_ranks(t_loc)
         if adopt_direct_exchange(a.exchange, connected, all_ok, err_max, t_max, dt):
+            dt_loc_min, dt_loc_max = t_min, t_max
+            rccl_line = res
+            res = result("p2p", t_max, maxh_p2p, *prof)
+            for k in ("sparse_regime",):
+                if k in rccl_line:
+                    res[k] = rccl_line[k]
             trial = {"exchange": "rccl", "ms_per_step": dt / a.steps * 1e3, "p2p_selftest": True,
                      "max_abs_dbeta_p2p_vs_rccl": err_max}
-            exchange, dt, maxh = "p2p", t_max, maxh_p2p
-            ev_ms, launches, alg_bytes = prof
+        res["exchange_trial"] = trial
+        if exch_us:
+            res["exchange_latency_us"] = dict(exch_us, doubles=rec_doubles, how="200 back-to-back all-reduces, HIP events")
         try:
             f.p2p_enable(False)
         except Exception:
             pass
 
-    updates = a.steps * a.cols
-    value = updates / dt
-    esz = np.dtype(dtype).itemsize
-    # roofline of the dominant (column-streaming) kernel, per launch, this rank's shard
-    achieved = alg_bytes / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else 0.0
-    stream_model = esz * n_local * 5.0 * updates / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else 0.0
-    kernel = ("k_gramstep" if a.block >= 16 else "k_blockstep") if a.mode == "block" else "k_step"
-    res = {
-        "metric": "coord_updates_per_sec", "value": value, "unit": "coord-updates/s",
-        "n_gpus": cp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype,
-        "data": "synthetic",
-        "config": {"workload": f"lasso_full_cyclic_sweep_gaussian_n{a.rows}_p{a.cols}_{a.dtype}_allmove",
-                   "n": a.rows, "p": a.cols, "s": a.planted, "noise": a.noise, "lambda_over_lambda_max": a.lam_frac,
-                   "sweep_mode": a.mode + (str(a.block) if a.mode == "block" else ""),
-                   "parallelism": f"rows{cp.world}", "exchange": exchange if cp.world > 1 else None,
-                   "moved_per_sweep": moved, "last_maxH": maxh},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": profiled_traffic(kernel, n_local, a.cols, a.dtype, a.block if a.mode == "block" else 1),
-                     "kernel": kernel,
-                     "launches": launches, "avg_launch_us": ev_ms * 1e3 / max(launches, 1),
-                     "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
-                     "stream_model_5n_GBps": stream_model,
-                     "floor_X_once_GBps": esz * n_local * updates / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else 0.0},
-    }
-    if sparse is not None:
-        res["sparse_regime"] = sparse
-    if trial is not None:
-        res["exchange_trial"] = trial
-    if exch_us:
-        res["exchange_latency_us"] = dict(exch_us, doubles=rec_doubles, how="200 back-to-back all-reduces, HIP events")
     if cp.rank == 0 and cp.world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(f, n_local, g.lambda0)
         res["cpu_baseline"] = cb[1]
@@ -321,6 +395,8 @@ def main():
         mt = [v for k, v in cb.items() if k != 1]
         if mt:
             res["cpu_baseline_all_cores"] = mt[0]
+    if cp.rank == 0 and cp.world == 1 and not a.no_cfg1 and not a.no_cpu_baseline:
+        res["cfg1"] = cfg1_cpu_vs_gpu(device)
     if cp.rank == 0:
         print(json.dumps(res), flush=True)
     f.close()

@@ -16,7 +16,12 @@ CSRC = os.path.join(_HERE, "csrc")
 # CDHIP_SO selects another build of the same library (kernel experiments); default is in-tree.
 SO_PATH = os.environ.get("CDHIP_SO") or os.path.join(CSRC, "libcdhip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "cdhip.h")
-SOURCES = ["cdhip.hip", "kernels.hpp", "gram_kernels.hpp", "sparse_iterate.hpp"]
+
+
+def _sources():
+    """Everything under csrc/ the library is compiled from (globbed: a new header cannot be forgotten)."""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+
 
 CDH_OK, CDH_DIM_MISMATCH, CDH_BAD_ARG, CDH_DOMAIN, CDH_HIP_ERROR, CDH_RCCL_ERROR, CDH_OOM = range(7)
 CDH_F64, CDH_F32 = 0, 1
@@ -51,11 +56,15 @@ class cdh_stats(C.Structure):
                 ("lambda_max", C.c_double)]
 
 
+# int32_t (*cdh_host_allreduce_fn)(void *user, double *inout, int64_t count)
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+
+
 def needs_build() -> bool:
     if not os.path.exists(SO_PATH):
         return True
     t = os.path.getmtime(SO_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    deps = [os.path.join(CSRC, s) for s in _sources()] + [HEADER]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -101,6 +110,7 @@ def lib():
         "cdh_set_y": [vp, vp],
         "cdh_get_y": [vp, vp],
         "cdh_set_obs_weights": [vp, vp],
+        "cdh_set_loss": [vp, i32],
         "cdh_generate": [vp, C.c_uint64, i64, f64, vp],
         "cdh_set_penalty": [vp, f64, vp, i64],
         "cdh_num_coordinates": [vp, P(i64)],
@@ -130,6 +140,8 @@ def lib():
         "cdh_p2p_connect": [vp, vp, i32, i32],
         "cdh_p2p_enable": [vp, i32],
         "cdh_exchange_probe": [vp, vp, i64],
+        "cdh_set_host_exchange": [vp, HOST_ALLREDUCE_FN, vp, i32, i32],
+        "cdh_exchange_stats": [vp, P(i64), P(i64), P(i64), P(i32)],
         "cdh_exchange_latency": [vp, i64, i32, P(f64)],
         "cdh_profile_begin": [vp],
         "cdh_profile_end": [vp, P(f64), P(i64), P(f64)],

@@ -284,7 +284,8 @@ class _HipLoss(CoordinateDifferentiableFunction):
         check(self._L.cdh_set_sweep_mode(self._h, int(mode), int(block)), self._h)
 
     def set_screening(self, on=True):
-        check(self._L.cdh_set_screening(self._h, int(bool(on))), self._h)
+        """0 / False: never; 1 / True: full passes of the solves (default); 2: cdPass_ as well."""
+        check(self._L.cdh_set_screening(self._h, int(on)), self._h)
 
     def set_use_graph(self, on=True):
         check(self._L.cdh_set_use_graph(self._h, int(bool(on))), self._h)
@@ -306,6 +307,30 @@ class _HipLoss(CoordinateDifferentiableFunction):
 
     def p2p_enable(self, on=True):
         check(self._L.cdh_p2p_enable(self._h, int(bool(on))), self._h)
+
+    def set_host_exchange(self, fn, rank, nranks):
+        """Bring-your-own transport: `fn(array_of_doubles)` must sum the array in place over all ranks
+        (cdh_set_host_exchange).  The ctypes trampoline is kept alive on the loss."""
+        if fn is None:
+            check(self._L.cdh_set_host_exchange(self._h, _lib.HOST_ALLREDUCE_FN(0), None, 0, 1), self._h)
+            self._host_cb = None
+            return
+
+        def tramp(_user, ptr, count):
+            try:
+                fn(np.ctypeslib.as_array(ptr, shape=(count,)))
+                return 0
+            except Exception:      # nothing may unwind into the library
+                return 1
+        cb = _lib.HOST_ALLREDUCE_FN(tramp)
+        check(self._L.cdh_set_host_exchange(self._h, cb, None, int(rank), int(nranks)), self._h)
+        self._host_cb = cb
+
+    def exchange_stats(self):
+        """All-reduces issued through each exchange so far, and the rank count the active one reports."""
+        a, b, c, n = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        check(self._L.cdh_exchange_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)), self._h)
+        return {"rccl_calls": a.value, "p2p_calls": b.value, "host_calls": c.value, "nranks": n.value}
 
     def exchange_probe(self, values):
         """All-reduce (sum) up to 4096 doubles through the active exchange; returns the sums."""

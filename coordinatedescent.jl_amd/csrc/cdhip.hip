@@ -37,6 +37,7 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     void* CommInitRank = nullptr;  // (ncclComm_t*, int nranks, ncclUniqueId by value, int rank)
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -58,6 +59,7 @@ bool load_rccl(std::string& err) {
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(
         g_rccl.lib, "ncclAllReduce");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    g_rccl.CommCount = (int (*)(void*, int*))dlsym(g_rccl.lib, "ncclCommCount");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) {
         err = "librccl is missing ncclGetUniqueId/ncclCommInitRank/ncclAllReduce";
         return false;
@@ -98,12 +100,14 @@ struct cdh_handle_s {
     cdh::SupportList x;
     int mode = CDH_SWEEP_BLOCK, blockB = 32;   // the fastest width on one GPU; cdh_set_sweep_mode changes it
     bool use_graph = false;
-    bool screening = true;        // solves screen their full passes over sparse iterates
+    int screening = 1;            // 0 never, 1 the solves' full passes over sparse iterates, 2 cdh_pass too
     bool reuse_residual = false;  // warm starts skip initialize! when r is known to match beta
     bool r_consistent = false;    // r == y - X beta (up to rounding) for the handle's current iterate
     bool chunk_dup = false;       // the current chunk's visit list repeats a coordinate
     std::vector<int32_t> stamp;   // duplicate detection scratch, size p
-    std::vector<std::pair<uint64_t, hipGraphExec_t>> graphs;  // captured chunk launch sequences
+    struct GraphEntry { uint64_t key; hipGraphExec_t exec; unsigned exchanges; unsigned rccl; };
+    std::vector<GraphEntry> graphs;  // captured chunk launch sequences
+    bool graph_broken = false;       // a capture failed on this handle: launch node by node from now on
     bool domain_error = false;
     int step_grid = 1, block_grid = 1, gram_per_cu = 2, cus = 1, gram32_per_cu = 1;
     int lt_per_cu = 0;  // experiments: blocks per CU of the LDS-transposed variants (0 = by tile size)
@@ -122,6 +126,15 @@ struct cdh_handle_s {
     unsigned p2p_epoch = 0, p2p_spin_limit = cdk::kP2PSpinLimit;
     int p2p_ranks = 0;
     bool p2p_on = false, p2p_dead = false;
+    unsigned* d_p2p_base = nullptr;   // epoch base of a replayed graph's exchanges (device memory)
+    bool capturing = false;           // run_chunk is recording a graph: exchanges take base + offset epochs
+    unsigned cap_exchanges = 0, cap_rccl = 0;   // exchanges recorded in the graph being captured
+    // bring-your-own transport (cdh_set_host_exchange): staged through pinned host memory
+    cdh_host_allreduce_fn host_fn = nullptr;
+    void* host_user = nullptr;
+    double* h_xchg = nullptr;
+    size_t h_xchg_doubles = 0;
+    int64_t n_rccl_calls = 0, n_p2p_calls = 0, n_host_calls = 0;
     // profile
     bool prof = false;
     double prof_ms = 0.0, prof_bytes = 0.0;
@@ -155,6 +168,16 @@ int32_t fail(cdh_handle h, int32_t code, const char* msg) {
     return code;
 }
 
+// every export checks what it dereferences: a NULL handle or out-pointer is CDH_BAD_ARG, never a crash
+#define NEED_H(h)                                                              \
+    do {                                                                       \
+        if (!(h)) return fail(nullptr, CDH_BAD_ARG, "handle is NULL");         \
+    } while (0)
+#define NEED_P(h, ptr)                                                         \
+    do {                                                                       \
+        if (!(ptr)) return fail((h), CDH_BAD_ARG, #ptr " is NULL");            \
+    } while (0)
+
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // Grid size for a grid-stride kernel with `units` work items and at most `gmax` resident blocks.
@@ -175,7 +198,9 @@ int32_t upload_ctrl(cdh_handle h) {
     return CDH_OK;
 }
 
-inline bool sharded(const cdh_handle_s* h) { return h->comm != nullptr || h->p2p_on; }
+// p2p_dead counts: a shard that lost its exchange must never fall into the single-process (fused)
+// finalize kernels on its local rows -- every path then reaches allreduce(), which refuses
+inline bool sharded(const cdh_handle_s* h) { return h->comm != nullptr || h->p2p_on || h->p2p_dead || h->host_fn != nullptr; }
 
 int32_t p2p_check(cdh_handle h) {
     // after a timeout the ranks no longer agree on what has been exchanged: the handle refuses every
@@ -190,19 +215,44 @@ int32_t p2p_check(cdh_handle h) {
 }
 
 static_assert(GramRec<4>::N <= cdk::kP2PMaxCount, "the widest block record must fit one inbox slot");
-// the arguments of the next direct exchange (epochs count exchanges; 0 means "never written")
+// Epochs count direct exchanges; 0 means "never written".  Consecutive epochs must alternate the
+// inbox slot (parity), also across the 32-bit wrap.
+constexpr unsigned kEpochWrap = 0xfffffff0u;
+inline unsigned epoch_after(unsigned e) { return e >= kEpochWrap ? ((e & 1u) ? 2u : 3u) : e + 1u; }
+// the arguments of the next direct exchange.  While a graph is being recorded the epoch is
+// (device-resident base) + (position of the exchange in the graph), so one graph serves every replay.
 cdk::P2PCall next_p2p_call(cdh_handle h) {
-    h->p2p_epoch = h->p2p_epoch == 0xffffffffu ? 2u : h->p2p_epoch + 1u;
-    return cdk::P2PCall{h->p2p_peers, h->rank, h->p2p_ranks, h->p2p_epoch, h->p2p_spin_limit, h->p2p_timeout};
+    if (h->capturing) {
+        h->cap_exchanges += 1;
+        return cdk::P2PCall{h->p2p_peers, h->rank, h->p2p_ranks, h->cap_exchanges, h->p2p_spin_limit, h->p2p_timeout, h->d_p2p_base};
+    }
+    h->p2p_epoch = epoch_after(h->p2p_epoch);
+    return cdk::P2PCall{h->p2p_peers, h->rank, h->p2p_ranks, h->p2p_epoch, h->p2p_spin_limit, h->p2p_timeout, nullptr};
 }
 
+// The one exchange seam of the row-sharded path: sum `count` doubles at dbuf (device) over all ranks,
+// in stream order.  Behind it: the direct exchange (short records), RCCL, or a caller-supplied host
+// transport.  Not sharded: nothing to do.
 int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
+    if (h->host_fn) {
+        if (h->capturing) return fail(h, CDH_BAD_ARG, "the host-staged exchange cannot be recorded in a graph");
+        if (count > h->h_xchg_doubles) return fail(h, CDH_BAD_ARG, "host exchange: record longer than the staging buffer");
+        HIPCHK(h, hipMemcpyAsync(h->h_xchg, dbuf, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const int32_t rc = h->host_fn(h->host_user, h->h_xchg, (int64_t)count);
+        if (rc != 0) return fail(h, CDH_RCCL_ERROR, "the host exchange callback reported a failure");
+        HIPCHK(h, hipMemcpyAsync(dbuf, h->h_xchg, sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // the staging buffer is reused by the next exchange
+        h->n_host_calls += 1;
+        return CDH_OK;
+    }
     if (h->p2p_on && (count <= (size_t)cdk::kP2PMaxCount || !h->comm)) {
         CHK(p2p_check(h));
         for (size_t o = 0; o < count; o += cdk::kP2PMaxCount) {
             const int c = (int)std::min<size_t>(cdk::kP2PMaxCount, count - o);
             hipLaunchKernelGGL(cdk::k_p2p_allreduce, dim3((c + 255) / 256), dim3(256), 0, h->stream, dbuf + o, c,
                                next_p2p_call(h));
+            if (!h->capturing) h->n_p2p_calls += 1;
         }
         HIPCHK(h, hipGetLastError());
         return CDH_OK;
@@ -215,6 +265,7 @@ int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
                  (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
         return CDH_RCCL_ERROR;
     }
+    if (h->capturing) h->cap_rccl += 1; else h->n_rccl_calls += 1;
     return CDH_OK;
 }
 
@@ -444,33 +495,55 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
             return launch_block_chunk<T, 2>(h, m);
         });
     };
-    // hipGraph replay: the launch sequence of an m-visit chunk depends only on (m, mode, B) --
+    // hipGraph replay: the launch sequence of an m-visit chunk depends only on (m, mode, B, exchange) --
     // every kernel takes its visit position as a literal and reads idx / hs / lambda from device
-    // memory -- so one captured graph serves every later pass of that length.  (Not used with a
-    // communicator: RCCL calls are left out of stream capture.)
-    if (h->use_graph && !sharded(h)) {
-        const uint64_t key = ((uint64_t)m << 16) | ((uint64_t)(blocked ? h->blockB : 0) << 4) |
+    // memory -- so one captured graph serves every later pass of that length.  Row shards too: the
+    // direct exchange reads its epoch base from device memory (set before each replay), RCCL
+    // all-reduces are recorded by RCCL itself as graph nodes.  Only the host-staged exchange cannot
+    // be recorded.  A failed capture switches the handle back to node-by-node launches for good.
+    bool launched = false;
+    if (h->use_graph && !h->graph_broken && !h->host_fn && !h->p2p_dead) {
+        const uint64_t key = ((uint64_t)m << 20) | ((uint64_t)(blocked ? h->blockB : 0) << 8) |
+                             (h->comm ? 32u : 0u) | (h->p2p_on ? 16u : 0u) |
                              (h->chunk_dup ? 4u : 0u) | (h->has_w ? 2u : 0u) | (h->nt ? 1u : 0u);
-        hipGraphExec_t exec = nullptr;
-        for (auto& e : h->graphs) if (e.first == key) exec = e.second;
-        if (!exec) {
+        cdh_handle_s::GraphEntry* entry = nullptr;
+        for (auto& e : h->graphs) if (e.key == key) entry = &e;
+        if (!entry) {
             hipGraph_t graph = nullptr;
-            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            const int32_t erc = enqueue();
-            HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
-            if (erc != CDH_OK) { (void)hipGraphDestroy(graph); return erc; }
-            HIPCHK(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            HIPCHK(h, hipGraphDestroy(graph));
-            if (h->graphs.size() >= 32) {  // bounded cache: drop the oldest
-                (void)hipGraphExecDestroy(h->graphs.front().second);
-                h->graphs.erase(h->graphs.begin());
+            hipGraphExec_t exec = nullptr;
+            h->capturing = true; h->cap_exchanges = 0; h->cap_rccl = 0;
+            hipError_t e0 = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+            const int32_t erc = e0 == hipSuccess ? enqueue() : (int32_t)CDH_HIP_ERROR;
+            hipError_t e1 = e0 == hipSuccess ? hipStreamEndCapture(h->stream, &graph) : e0;
+            h->capturing = false;
+            if (erc == CDH_OK && e1 == hipSuccess && graph) e1 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (erc != CDH_OK || e1 != hipSuccess || !exec) {
+                (void)hipGetLastError();
+                h->graph_broken = true;
+            } else {
+                if (h->graphs.size() >= 32) {  // bounded cache: drop the oldest
+                    (void)hipGraphExecDestroy(h->graphs.front().exec);
+                    h->graphs.erase(h->graphs.begin());
+                }
+                h->graphs.push_back({key, exec, h->cap_exchanges, h->cap_rccl});
+                entry = &h->graphs.back();
             }
-            h->graphs.emplace_back(key, exec);
         }
-        HIPCHK(h, hipGraphLaunch(exec, h->stream));
-    } else {
-        CHK(enqueue());
+        if (entry) {
+            if (entry->exchanges) {
+                // epochs base+1 .. base+exchanges; across the 32-bit wrap the slot parity keeps alternating
+                if (h->p2p_epoch + entry->exchanges >= kEpochWrap) h->p2p_epoch = (h->p2p_epoch & 1u) ? 1u : 2u;
+                hipLaunchKernelGGL(cdk::k_set_u32, dim3(1), dim3(1), 0, h->stream, h->d_p2p_base, h->p2p_epoch);
+                h->p2p_epoch += entry->exchanges;
+                h->n_p2p_calls += entry->exchanges;
+            }
+            h->n_rccl_calls += entry->rccl;
+            HIPCHK(h, hipGraphLaunch(entry->exec, h->stream));
+            launched = true;
+        }
     }
+    if (!launched) CHK(enqueue());
     HIPCHK(h, hipGetLastError());
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_hs, h->d_hs, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
@@ -481,7 +554,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     CHK(p2p_check(h));
     if (h->h_ctrl->domain_error) h->domain_error = true;
     const double mh = h->h_ctrl->maxH;
-    if (mh > *maxH || mh != mh) *maxH = mh;
+    if (mh > *maxH) *maxH = mh;   // a NaN h never raises maxH: `abs(h) > maxH` (coordinate_descent.jl:104)
     // replay the SparseIterate writes of the visits in order (x[k] += b/a ; cdprox!)
     for (int i = 0; i < m; ++i) {
         const int64_t k = idx0[i];
@@ -647,8 +720,10 @@ void free_all(cdh_handle h) {
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (void* m : h->p2p_mapped) (void)hipIpcCloseMemHandle(m);
     if (h->p2p_inbox) (void)hipFree(h->p2p_inbox);
+    if (h->d_p2p_base) (void)hipFree(h->d_p2p_base);
+    if (h->h_xchg) (void)hipHostFree(h->h_xchg);
     if (h->p2p_timeout) (void)hipHostFree(h->p2p_timeout);
-    for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
+    for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);
     void* dev[] = {h->X, h->y, h->r, h->w, h->beta, h->omega, h->d_ctrl, h->d_idx, h->d_hs, h->d_newval,
                    h->d_touched, h->d_partials, h->d_red, h->d_colout, h->d_sup_idx, h->d_sup_val};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -666,6 +741,7 @@ void free_all(cdh_handle h) {
 extern "C" {
 
 int32_t cdh_device_count(int32_t* out) {
+    NEED_P(nullptr, out);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { g_create_error = hipGetErrorString(e); *out = 0; return CDH_HIP_ERROR; }
@@ -779,11 +855,14 @@ int32_t cdh_destroy(cdh_handle h) {
 }
 
 int32_t cdh_synchronize(cdh_handle h) {
+    NEED_H(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return CDH_OK;
 }
 
 int32_t cdh_set_X_cols(cdh_handle h, int64_t j0, int64_t ncols, const void* host, int64_t ld) {
+    NEED_H(h);
+    if (ncols > 0) NEED_P(h, host);
     h->r_consistent = false;
     if (j0 < 0 || ncols < 0 || j0 + ncols > h->p || ld < h->n) return fail(h, CDH_DIM_MISMATCH, "column block outside X");
     if (ncols == 0) return CDH_OK;
@@ -796,6 +875,8 @@ int32_t cdh_set_X_cols(cdh_handle h, int64_t j0, int64_t ncols, const void* host
 }
 
 int32_t cdh_get_X_cols(cdh_handle h, int64_t j0, int64_t ncols, void* host, int64_t ld) {
+    NEED_H(h);
+    if (ncols > 0) NEED_P(h, host);
     if (j0 < 0 || ncols < 0 || j0 + ncols > h->p || ld < h->n) return fail(h, CDH_DIM_MISMATCH, "column block outside X");
     if (ncols == 0) return CDH_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -807,6 +888,8 @@ int32_t cdh_get_X_cols(cdh_handle h, int64_t j0, int64_t ncols, void* host, int6
 }
 
 int32_t cdh_set_y(cdh_handle h, const void* host_y) {
+    NEED_H(h);
+    NEED_P(h, host_y);
     h->r_consistent = false;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(h->y, host_y, (size_t)h->n * h->esz, hipMemcpyHostToDevice, h->stream));
@@ -817,19 +900,46 @@ int32_t cdh_set_y(cdh_handle h, const void* host_y) {
 }
 
 int32_t cdh_get_y(cdh_handle h, void* host_y) {
+    NEED_H(h);
+    NEED_P(h, host_y);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(host_y, h->y, (size_t)h->n * h->esz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return CDH_OK;
 }
 
+static int32_t ensure_weights_buffer(cdh_handle h) {
+    if (h->w) return CDH_OK;
+    const size_t colbytes = (size_t)h->ld * h->esz;
+    HIPCHK(h, hipMalloc(&h->w, colbytes));
+    HIPCHK(h, hipMemsetAsync(h->w, 0, colbytes, h->stream));
+    return CDH_OK;
+}
+
 int32_t cdh_set_obs_weights(cdh_handle h, const void* host_w) {
+    NEED_H(h);
+    NEED_P(h, host_w);
     h->r_consistent = false;
     if (h->loss != CDH_WLS) return fail(h, CDH_BAD_ARG, "observation weights need the CDH_WLS loss");
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_weights_buffer(h));
     HIPCHK(h, hipMemcpyAsync(h->w, host_w, (size_t)h->n * h->esz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->has_w = true;
+    return CDH_OK;
+}
+
+int32_t cdh_set_loss(cdh_handle h, int32_t loss) {
+    NEED_H(h);
+    if (loss != CDH_LS && loss != CDH_SQRT && loss != CDH_WLS) return fail(h, CDH_BAD_ARG, "unknown loss");
+    if (loss == h->loss) return CDH_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (loss == CDH_WLS) CHK(ensure_weights_buffer(h));
+    h->loss = loss;
+    h->ctrl.loss = loss;          // goes to the device with the next chunk's control block
+    h->has_w = false;             // a weighted loss gets its weights from cdh_set_obs_weights
+    h->r_consistent = false;
+    h->domain_error = false;
     return CDH_OK;
 }
 
@@ -891,11 +1001,17 @@ static int32_t cdh_set_penalty_impl(cdh_handle h, double lambda0, const double* 
     return CDH_OK;
 }
 
-int32_t cdh_num_coordinates(cdh_handle h, int64_t* out) { *out = h->p; return CDH_OK; }
+int32_t cdh_num_coordinates(cdh_handle h, int64_t* out) {
+    NEED_H(h);
+    NEED_P(h, out);
+    *out = h->p;
+    return CDH_OK;
+}
 
 static int32_t cdh_set_iterate_impl(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t* idx1, const double* val) {
     if (x_length != h->p) return fail(h, CDH_DIM_MISMATCH, "numCoordinates(x) != numCoordinates(f)");
     if (nnz < 0 || nnz > h->p) return fail(h, CDH_BAD_ARG, "nnz out of range");
+    if (nnz > 0) { NEED_P(h, idx1); NEED_P(h, val); }
     for (int64_t i = 0; i < nnz; ++i)
         if (idx1[i] < 1 || idx1[i] > h->p) return fail(h, CDH_BAD_ARG, "support index out of range");
     HIPCHK(h, hipSetDevice(h->device));
@@ -923,6 +1039,7 @@ static int32_t cdh_initialize_impl(cdh_handle h, int64_t x_length, int64_t nnz, 
 }
 
 static int32_t cdh_gradient_impl(cdh_handle h, int64_t k1, double* out) {
+    NEED_P(h, out);
     if (k1 < 1 || k1 > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
     HIPCHK(h, hipSetDevice(h->device));
     CHK(col_dots(h, k1 - 1, 1, h->r, h->loss == CDH_WLS));
@@ -954,17 +1071,19 @@ static int32_t cdh_descend_impl(cdh_handle h, int64_t k1, double* out_h) {
     int32_t rc = run_chunk(h, &k0, 1, &maxH);  // no dropzeros!: that is _cdPass!'s job
     h->mode = save_mode;
     if (rc != CDH_OK) return rc;
-    *out_h = h->h_hs[0];
+    if (out_h) *out_h = h->h_hs[0];
     return CDH_OK;
 }
 
 static int32_t cdh_lambda_max_impl(cdh_handle h, double* out) {
+    NEED_P(h, out);
     HIPCHK(h, hipSetDevice(h->device));
     return lambda_max(h, out);
 }
 
 static int32_t cdh_pass_impl(cdh_handle h, int64_t m, const int64_t* idx1, double* out_maxH) {
     if (m < 0) return fail(h, CDH_BAD_ARG, "m < 0");
+    if (m > 0) NEED_P(h, idx1);
     HIPCHK(h, hipSetDevice(h->device));
     std::vector<int64_t> idx0((size_t)m);
     for (int64_t i = 0; i < m; ++i) {
@@ -972,13 +1091,14 @@ static int32_t cdh_pass_impl(cdh_handle h, int64_t m, const int64_t* idx1, doubl
         idx0[(size_t)i] = idx1[i] - 1;
     }
     double maxH = 0.0;
-    if (m > 0) CHK(run_pass(h, idx0.data(), m, &maxH));
+    if (m > 0) CHK(run_pass(h, idx0.data(), m, &maxH, h->screening >= 2));
     else h->x.dropzeros();
     if (out_maxH) *out_maxH = maxH;
     return CDH_OK;
 }
 
 static int32_t cdh_solve_impl(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
+    NEED_P(h, opt);
     HIPCHK(h, hipSetDevice(h->device));
     cdh_stats st{};
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
@@ -988,6 +1108,7 @@ static int32_t cdh_solve_impl(cdh_handle h, const cdh_options* opt, cdh_stats* o
 }
 
 static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
+    NEED_P(h, opt);
     HIPCHK(h, hipSetDevice(h->device));
     cdh_stats st{};
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
@@ -999,44 +1120,54 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
         if (!(h->reuse_residual && h->r_consistent)) CHK(rebuild_residual(h));
         rc = solve(h, opt, sched, &st);
     } else {
-        h->x.clear();                                   // fill!(x, 0)           (:25)
-        CHK(rebuild_residual(h));                       // initialize!(f, x)     (:26)
-        double lmax = 0.0;
-        CHK(lambda_max(h, &lmax));                      // _findLambdaMax        (:29)
-        st.lambda_max = lmax;
-        const double target = h->ctrl.lambda0;
-        const double l1 = std::log(lmax), l2 = std::log(target);
-        const double step = (l2 - l1) / (double)opt->numSteps;
-        if (step == 0.0 || step != step) {
-            rc = fail(h, CDH_BAD_ARG, "cold start: the range log(lambda_max):step:log(lambda0) has a zero step");
-        } else {
-            for (int64_t j = 0; j <= opt->numSteps && rc == CDH_OK; ++j) {  // (:32-36)
+        const double target = h->ctrl.lambda0;          // g itself is never mutated by the reference:
+        rc = [&]() -> int32_t {                         // whatever happens below, lambda0 is put back
+            h->x.clear();                               // fill!(x, 0)           (:25)
+            CHK(rebuild_residual(h));                   // initialize!(f, x)     (:26)
+            double lmax = 0.0;
+            CHK(lambda_max(h, &lmax));                  // _findLambdaMax        (:29)
+            st.lambda_max = lmax;
+            const double l1 = std::log(lmax), l2 = std::log(target);
+            const double step = (l2 - l1) / (double)opt->numSteps;
+            if (step == 0.0 || step != step)
+                return fail(h, CDH_BAD_ARG, "cold start: the range log(lambda_max):step:log(lambda0) has a zero step");
+            for (int64_t j = 0; j <= opt->numSteps; ++j) {  // (:32-36)
                 const double l = (j == opt->numSteps) ? l2 : l1 + (double)j * step;
                 h->ctrl.lambda0 = std::exp(l);
-                rc = solve(h, opt, sched, &st);
+                CHK(solve(h, opt, sched, &st));
             }
+            return CDH_OK;
+        }();
+        h->ctrl.lambda0 = target;
+        if (rc == CDH_OK) {
+            CHK(upload_ctrl(h));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
         }
-        h->ctrl.lambda0 = target;  // g itself is never mutated by the reference
-        CHK(upload_ctrl(h));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     if (out) *out = st;
     return rc;
 }
 
 int32_t cdh_get_beta(cdh_handle h, double* out_p) {
+    NEED_H(h);
+    NEED_P(h, out_p);
     std::memset(out_p, 0, sizeof(double) * (size_t)h->p);
     for (int64_t s = 0; s < h->x.nnz(); ++s) out_p[h->x.coord(s)] = h->x.slot_value(s);
     return CDH_OK;
 }
 
 int32_t cdh_get_support(cdh_handle h, int64_t* out_idx1, int64_t* out_nnz) {
+    NEED_H(h);
+    NEED_P(h, out_idx1);
+    NEED_P(h, out_nnz);
     for (int64_t s = 0; s < h->x.nnz(); ++s) out_idx1[s] = h->x.coord(s) + 1;
     *out_nnz = h->x.nnz();
     return CDH_OK;
 }
 
 int32_t cdh_get_residual(cdh_handle h, void* out_n_local) {
+    NEED_H(h);
+    NEED_P(h, out_n_local);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(out_n_local, h->r, (size_t)h->n * h->esz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1044,6 +1175,7 @@ int32_t cdh_get_residual(cdh_handle h, void* out_n_local) {
 }
 
 static int32_t cdh_col_rms_impl(cdh_handle h, double* out_p) {
+    NEED_P(h, out_p);
     HIPCHK(h, hipSetDevice(h->device));
     CHK(col_dots(h, 0, h->p, h->r, false));
     std::vector<double> cd((size_t)(2 * h->p));
@@ -1054,6 +1186,7 @@ static int32_t cdh_col_rms_impl(cdh_handle h, double* out_p) {
 }
 
 static int32_t cdh_xt_r_impl(cdh_handle h, double* out_p) {
+    NEED_P(h, out_p);
     HIPCHK(h, hipSetDevice(h->device));
     CHK(col_dots(h, 0, h->p, h->r, false));
     std::vector<double> cd((size_t)(2 * h->p));
@@ -1065,6 +1198,8 @@ static int32_t cdh_xt_r_impl(cdh_handle h, double* out_p) {
 
 static int32_t cdh_gram_impl(cdh_handle h, int64_t m, const int64_t* idx1, double* out_G, double* out_c, double* out_q) {
     if (m < 1 || m > 64) return fail(h, CDH_BAD_ARG, "need 1 <= m <= 64 columns");
+    NEED_P(h, idx1);
+    NEED_P(h, out_G);
     for (int64_t i = 0; i < m; ++i)
         if (idx1[i] < 1 || idx1[i] > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1098,9 +1233,14 @@ static int32_t cdh_gram_impl(cdh_handle h, int64_t m, const int64_t* idx1, doubl
     return CDH_OK;
 }
 
-int32_t cdh_set_reuse_residual(cdh_handle h, int32_t on) { h->reuse_residual = on != 0; return CDH_OK; }
+int32_t cdh_set_reuse_residual(cdh_handle h, int32_t on) {
+    NEED_H(h);
+    h->reuse_residual = on != 0;
+    return CDH_OK;
+}
 
 int32_t cdh_resid_moments(cdh_handle h, double* out_sum, double* out_sumsq) {
+    NEED_H(h);
     HIPCHK(h, hipSetDevice(h->device));
     CHK(resid_moments_dev(h));
     HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1111,6 +1251,7 @@ int32_t cdh_resid_moments(cdh_handle h, double* out_sum, double* out_sumsq) {
 }
 
 static int32_t cdh_objective_impl(cdh_handle h, double* out) {
+    NEED_P(h, out);
     HIPCHK(h, hipSetDevice(h->device));
     CHK(resid_moments_dev(h));
     HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1126,6 +1267,7 @@ static int32_t cdh_objective_impl(cdh_handle h, double* out) {
 }
 
 int32_t cdh_set_sweep_mode(cdh_handle h, int32_t mode, int32_t block) {
+    NEED_H(h);
     if (mode != CDH_SWEEP_COORD && mode != CDH_SWEEP_BLOCK) return fail(h, CDH_BAD_ARG, "unknown sweep mode");
     if (mode == CDH_SWEEP_BLOCK && block != 2 && block != 4 && block != 8 && block != 16 && block != 32 && block != 64)
         return fail(h, CDH_BAD_ARG, "block size must be 2, 4, 8, 16, 32 or 64");
@@ -1134,11 +1276,22 @@ int32_t cdh_set_sweep_mode(cdh_handle h, int32_t mode, int32_t block) {
     return CDH_OK;
 }
 
-int32_t cdh_set_screening(cdh_handle h, int32_t on) { h->screening = on != 0; return CDH_OK; }
+int32_t cdh_set_screening(cdh_handle h, int32_t on) {
+    NEED_H(h);
+    if (on < 0 || on > 2) return fail(h, CDH_BAD_ARG, "screening: 0 = never, 1 = solves, 2 = cdh_pass as well");
+    h->screening = on;
+    return CDH_OK;
+}
 
-int32_t cdh_set_use_graph(cdh_handle h, int32_t on) { h->use_graph = on != 0; return CDH_OK; }
+int32_t cdh_set_use_graph(cdh_handle h, int32_t on) {
+    NEED_H(h);
+    h->use_graph = on != 0;
+    if (on) h->graph_broken = false;   // asking again retries a capture that failed earlier
+    return CDH_OK;
+}
 
 int32_t cdh_comm_unique_id(void* out_128_bytes) {
+    NEED_P(nullptr, out_128_bytes);
     std::string err;
     if (!load_rccl(err)) { g_create_error = err; return CDH_RCCL_ERROR; }
     UniqueId id;
@@ -1149,6 +1302,9 @@ int32_t cdh_comm_unique_id(void* out_128_bytes) {
 }
 
 int32_t cdh_comm_init(cdh_handle h, const void* id_128_bytes, int32_t rank, int32_t nranks) {
+    NEED_H(h);
+    NEED_P(h, id_128_bytes);
+    if (h->host_fn) return fail(h, CDH_BAD_ARG, "the handle already exchanges through a host transport");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, CDH_BAD_ARG, "bad rank / nranks");
     // a 1-rank communicator is only built when asked for (exercises the RCCL path on one GPU)
     if (nranks == 1 && !getenv("CDH_FORCE_RCCL")) { h->rank = 0; h->nranks = 1; return CDH_OK; }
@@ -1168,6 +1324,8 @@ int32_t cdh_comm_init(cdh_handle h, const void* id_128_bytes, int32_t rank, int3
 
 // ---- optional direct exchange (p2p_exchange.hpp) -------------------------------------------------
 int32_t cdh_p2p_local_handle(cdh_handle h, void* out_64_bytes) {
+    NEED_H(h);
+    NEED_P(h, out_64_bytes);
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size is part of the ABI");
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->p2p_inbox) {
@@ -1179,6 +1337,8 @@ int32_t cdh_p2p_local_handle(cdh_handle h, void* out_64_bytes) {
         }
         h->p2p_inbox = (unsigned long long*)q;
         HIPCHK(h, hipMemset(h->p2p_inbox, 0, kP2PInboxBytes));  // tag 0 = never written; epochs start at 1
+        HIPCHK(h, hipMalloc((void**)&h->d_p2p_base, sizeof(unsigned)));
+        HIPCHK(h, hipMemset(h->d_p2p_base, 0, sizeof(unsigned)));
         HIPCHK(h, hipHostMalloc((void**)&h->p2p_timeout, sizeof(int), hipHostMallocDefault));
         *h->p2p_timeout = 0;
         HIPCHK(h, hipDeviceSynchronize());
@@ -1190,6 +1350,9 @@ int32_t cdh_p2p_local_handle(cdh_handle h, void* out_64_bytes) {
 }
 
 int32_t cdh_p2p_connect(cdh_handle h, const void* handles_64_bytes_each, int32_t rank, int32_t nranks) {
+    NEED_H(h);
+    NEED_P(h, handles_64_bytes_each);
+    if (h->host_fn) return fail(h, CDH_BAD_ARG, "the handle already exchanges through a host transport");
     if (nranks < 1 || nranks > kP2PMaxRanks || rank < 0 || rank >= nranks)
         return fail(h, CDH_BAD_ARG, "p2p exchange: bad rank / nranks (at most 8 ranks)");
     if (!h->p2p_inbox) return fail(h, CDH_BAD_ARG, "cdh_p2p_local_handle must be called first");
@@ -1212,6 +1375,7 @@ int32_t cdh_p2p_connect(cdh_handle h, const void* handles_64_bytes_each, int32_t
 }
 
 int32_t cdh_p2p_enable(cdh_handle h, int32_t on) {
+    NEED_H(h);
     if (on && !h->p2p_ranks) return fail(h, CDH_BAD_ARG, "p2p exchange is not connected");
     if (on && *(volatile int*)h->p2p_timeout)
         return fail(h, CDH_RCCL_ERROR, "p2p exchange timed out earlier on this handle; it stays off");
@@ -1219,7 +1383,43 @@ int32_t cdh_p2p_enable(cdh_handle h, int32_t on) {
     return CDH_OK;
 }
 
+int32_t cdh_set_host_exchange(cdh_handle h, cdh_host_allreduce_fn fn, void* user, int32_t rank, int32_t nranks) {
+    NEED_H(h);
+    if (!fn) { h->host_fn = nullptr; h->host_user = nullptr; return CDH_OK; }
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, CDH_BAD_ARG, "bad rank / nranks");
+    if (h->comm || h->p2p_ranks) return fail(h, CDH_BAD_ARG, "the handle already has an exchange (RCCL / direct)");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->h_xchg) {   // the longest record is the 2p column dots of _findLambdaMax / _stdX!
+        h->h_xchg_doubles = (size_t)std::max<int64_t>(4096, 2 * h->p);
+        HIPCHK(h, hipHostMalloc((void**)&h->h_xchg, sizeof(double) * h->h_xchg_doubles));
+    }
+    h->host_fn = fn; h->host_user = user; h->rank = rank; h->nranks = nranks;
+    return CDH_OK;
+}
+
+int32_t cdh_exchange_stats(cdh_handle h, int64_t* out_rccl_calls, int64_t* out_p2p_calls, int64_t* out_host_calls,
+                           int32_t* out_nranks) {
+    NEED_H(h);
+    if (out_rccl_calls) *out_rccl_calls = h->n_rccl_calls;
+    if (out_p2p_calls) *out_p2p_calls = h->n_p2p_calls;
+    if (out_host_calls) *out_host_calls = h->n_host_calls;
+    if (out_nranks) {
+        int n = 1;
+        if (h->comm) {   // what the communicator itself says, not what we asked for
+            n = h->nranks;
+            if (g_rccl.CommCount && g_rccl.CommCount(h->comm, &n) != 0) n = -1;
+        } else if (h->p2p_on) {
+            n = h->p2p_ranks;
+        } else if (h->host_fn) {
+            n = h->nranks;
+        }
+        *out_nranks = n;
+    }
+    return CDH_OK;
+}
+
 int32_t cdh_exchange_probe(cdh_handle h, double* inout, int64_t count) {
+    NEED_H(h);
     if (count < 0 || count > 4096 || (count > 0 && !inout)) return fail(h, CDH_BAD_ARG, "probe: 0 <= count <= 4096");
     if (!h->d_red) return fail(h, CDH_BAD_ARG, "probe: handle has no data yet");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1231,6 +1431,7 @@ int32_t cdh_exchange_probe(cdh_handle h, double* inout, int64_t count) {
 }
 
 int32_t cdh_exchange_latency(cdh_handle h, int64_t count, int32_t iters, double* out_us) {
+    NEED_H(h);
     if (count < 1 || count > 4096 || iters < 1 || iters > 100000 || !out_us) return fail(h, CDH_BAD_ARG, "latency probe: 1 <= count <= 4096, 1 <= iters <= 100000");
     if (!h->d_red) return fail(h, CDH_BAD_ARG, "probe: handle has no data yet");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1249,11 +1450,13 @@ int32_t cdh_exchange_latency(cdh_handle h, int64_t count, int32_t iters, double*
 }
 
 int32_t cdh_profile_begin(cdh_handle h) {
+    NEED_H(h);
     h->prof = true; h->prof_ms = 0.0; h->prof_bytes = 0.0; h->prof_launches = 0;
     return CDH_OK;
 }
 
 int32_t cdh_profile_end(cdh_handle h, double* out_ms, int64_t* out_launches, double* out_algorithmic_bytes) {
+    NEED_H(h);
     h->prof = false;
     if (out_ms) *out_ms = h->prof_ms;
     if (out_launches) *out_launches = h->prof_launches;
@@ -1268,71 +1471,85 @@ int32_t cdh_profile_end(cdh_handle h, double* out_ms, int64_t* out_launches, dou
     catch (...) { return fail((h), CDH_BAD_ARG, "unknown C++ exception"); }
 
 int32_t cdh_pass(cdh_handle h, int64_t m, const int64_t* idx1, double* out_maxH) {
+    NEED_H(h);
     try { return cdh_pass_impl(h, m, idx1, out_maxH); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_solve(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
+    NEED_H(h);
     try { return cdh_solve_impl(h, opt, out); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_coordinate_descent(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
+    NEED_H(h);
     try { return cdh_coordinate_descent_impl(h, opt, out); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_initialize(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t* idx1, const double* val) {
+    NEED_H(h);
     try { return cdh_initialize_impl(h, x_length, nnz, idx1, val); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_set_iterate(cdh_handle h, int64_t x_length, int64_t nnz, const int64_t* idx1, const double* val) {
+    NEED_H(h);
     try { return cdh_set_iterate_impl(h, x_length, nnz, idx1, val); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_lambda_max(cdh_handle h, double* out) {
+    NEED_H(h);
     try { return cdh_lambda_max_impl(h, out); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_col_rms(cdh_handle h, double* out_p) {
+    NEED_H(h);
     try { return cdh_col_rms_impl(h, out_p); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_xt_r(cdh_handle h, double* out_p) {
+    NEED_H(h);
     try { return cdh_xt_r_impl(h, out_p); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_gram(cdh_handle h, int64_t m, const int64_t* idx1, double* out_G, double* out_c, double* out_q) {
+    NEED_H(h);
     try { return cdh_gram_impl(h, m, idx1, out_G, out_c, out_q); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_generate(cdh_handle h, uint64_t seed, int64_t s, double noise, double* out_beta_star) {
+    NEED_H(h);
     try { return cdh_generate_impl(h, seed, s, noise, out_beta_star); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_objective(cdh_handle h, double* out) {
+    NEED_H(h);
     try { return cdh_objective_impl(h, out); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_gradient(cdh_handle h, int64_t k1, double* out) {
+    NEED_H(h);
     try { return cdh_gradient_impl(h, k1, out); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_descend(cdh_handle h, int64_t k1, double* out_h) {
+    NEED_H(h);
     try { return cdh_descend_impl(h, k1, out_h); }
     CDH_CATCH(h)
 }
 
 int32_t cdh_set_penalty(cdh_handle h, double lambda0, const double* omega, int64_t n_omega) {
+    NEED_H(h);
     try { return cdh_set_penalty_impl(h, lambda0, omega, n_omega); }
     CDH_CATCH(h)
 }

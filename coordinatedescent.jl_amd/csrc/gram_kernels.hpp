@@ -510,16 +510,15 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
             b_me = fma(-h_s, gcol[s], b_me);   // only lanes > s still use b_me
         }
     }
-    // maxH over the block's visits (NaN sticks), then the stores
+    // maxH over the block's visits, then the stores.  A NaN h never raises maxH, as in the reference's
+    // `abs(h) > maxH` (coordinate_descent.jl:104-106)
     double ah = mine ? fabs(h_me) : 0.0;
-    const bool any_nan = __ballot(ah != ah) != 0ull;
     double m = (ah != ah) ? 0.0 : ah;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
     if (lane == 0) {
         double mh = maxH0;
         if (m > mh) mh = m;
-        if (any_nan || mh != mh) mh = __builtin_nan("");
         ctrl->maxH = mh;
         if (dom) ctrl->domain_error = 1;
     }

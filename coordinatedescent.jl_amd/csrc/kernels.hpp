@@ -315,7 +315,7 @@ __device__ inline void scalar_update(double a, double b, double q, Ctrl* ctrl, d
     newval[pos] = o.nv;
     touched[pos] = o.tch;
     const double ah = fabs(h);
-    if (ah > ctrl->maxH || ah != ah) ctrl->maxH = ah;  // NaN sticks
+    if (ah > ctrl->maxH) ctrl->maxH = ah;  // NaN never raises maxH (coordinate_descent.jl:104)
 }
 
 // Sum the per-block partials (value-major, G per value) in a fixed order: wave v sums
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const double* __restrict__ 
             const double h = o.nv - oldv;
             beta[k] = o.nv; hs[pos] = h; newval[pos] = o.nv; touched[pos] = o.tch;
             const double ah = fabs(h);
-            if (ah > ctrl->maxH || ah != ah) ctrl->maxH = ah;
+            if (ah > ctrl->maxH) ctrl->maxH = ah;
         } else {
             red[0] = sums[0]; red[1] = sums[1]; red[2] = sums[2]; red[3] = 0.0;
         }
@@ -552,7 +552,7 @@ __device__ inline void block_scalar_updates(const double* rec /* LDS or global *
             const double h = o.nv - oldv;
             s_nv[i] = o.nv; s_h[i] = h; s_t[i] = o.tch;
             const double ah = fabs(h);
-            if (ah > maxH || ah != ah) maxH = ah;
+            if (ah > maxH) maxH = ah;
             q = q - 2.0 * h * b + h * h * a;
             if (q < 0.0) q = 0.0;
         }

@@ -77,16 +77,22 @@ struct P2PCall {
     int rank, nranks;
     unsigned epoch, spin_limit;
     int* timeout_flag;
+    // replayed from a hipGraph: the exchange's epoch is *epoch_base + epoch (its position in the graph);
+    // the host sets the base before every replay.  nullptr: `epoch` is the epoch itself.
+    const unsigned* epoch_base;
 };
 // an exchange that already timed out poisons the ones queued behind it: they do not wait again
 __device__ __forceinline__ unsigned p2p_spin_budget(const P2PCall& c) {
     return *(volatile int*)c.timeout_flag ? 0u : c.spin_limit;
 }
 
+__global__ void k_set_u32(unsigned* dst, unsigned v) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v; }
+
 __global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ buf, int count, P2PCall c) {
     const unsigned limit = p2p_spin_budget(c);
+    const unsigned epoch = c.epoch_base ? *c.epoch_base + c.epoch : c.epoch;
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < count; v += gridDim.x * blockDim.x)
-        buf[v] = p2p_exchange_value(buf[v], v, c.peers, c.rank, c.nranks, c.epoch, limit, c.timeout_flag);
+        buf[v] = p2p_exchange_value(buf[v], v, c.peers, c.rank, c.nranks, epoch, limit, c.timeout_flag);
 }
 
 }  // namespace cdk

@@ -77,6 +77,14 @@ class ControlPlane:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def min_over_ranks(self, value: float) -> float:
+        if self.dist is None:
+            return value
+        import torch
+        t = torch.tensor([value], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
     def sum_over_ranks(self, value: float) -> float:
         if self.dist is None:
             return value
@@ -105,6 +113,24 @@ def connect(loss, cp: ControlPlane):
         uid = buf.raw
     uid = cp.broadcast_bytes(uid, 128, src=0)
     loss.comm_init(uid, cp.rank, cp.world)
+    return loss
+
+
+def connect_host(loss, cp: ControlPlane):
+    """Row-shard exchange over the control plane itself (cdh_set_host_exchange): every all-reduce of
+    the sweep is staged through pinned host memory and summed by torch.distributed (gloo).  Far slower
+    than RCCL or the direct exchange -- a stream round trip per exchange -- but it needs nothing from
+    the GPUs' interconnect, so it is the transport that works anywhere (and the one the tests use to
+    run the library's sharded launch sequence with several ranks on one GPU)."""
+    if cp.world == 1:
+        return loss
+    import torch
+
+    def allreduce(buf):
+        t = torch.from_numpy(buf)          # shares memory with the library's staging buffer
+        cp.dist.all_reduce(t, op=cp.dist.ReduceOp.SUM)
+
+    loss.set_host_exchange(allreduce, cp.rank, cp.world)
     return loss
 
 

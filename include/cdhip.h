@@ -112,6 +112,12 @@ int32_t cdh_set_y(cdh_handle h, const void *host_y);
 int32_t cdh_get_y(cdh_handle h, void *host_y);
 /* Observation weights of CDWeightedLSLoss. */
 int32_t cdh_set_obs_weights(cdh_handle h, const void *host_w);
+/* Which loss the resident X serves from now on.  The reference builds a new loss object around the
+ * same matrix for every front-end call (lasso.jl:33,48,71,93,117,245: CDLeastSquaresLoss(y, X),
+ * CDSqrtLassoLoss(y, X), CDWeightedLSLoss(y, X, w)); the binding keeps X in HBM across those objects
+ * and switches the handle to the kind of the loss it is called with.  Invalidates the carried
+ * residual; CDH_WLS needs cdh_set_obs_weights before the next sweep (weights are zero until then). */
+int32_t cdh_set_loss(cdh_handle h, int32_t loss);
 /* Synthetic Gaussian problem generated on the device from a counter-based
  * generator keyed (seed, global row, column), shapes of benchmark/cd_bench.jl:
  * 8-14: X_ij ~ N(0,1), beta*_j = z_j (1 + u_j) for j < s, y = X beta* + noise e.
@@ -186,9 +192,13 @@ int32_t cdh_set_reuse_residual(cdh_handle h, int32_t on);
 /* Full passes of cdh_solve / cdh_coordinate_descent over a sparse iterate are screened by
  * default: runs of visits that provably leave beta and r unchanged (beta_k == 0 and |X_k'r|
  * below the threshold) are settled from one dots-only pass over their columns; the iterates
- * are the same as visiting one by one.  cdh_pass never screens. */
+ * are the same as visiting one by one.  on: 0 = never, 1 = full passes of the solves (default; cdh_pass
+ * visits every column it is given), 2 = cdh_pass as well. */
 int32_t cdh_set_screening(cdh_handle h, int32_t on);
-/* Replay each pass from a captured hipGraph instead of individual launches. */
+/* Replay each pass from a captured hipGraph instead of individual launches (the north_star's
+ * "full sweep captured under hipGraph").  Works on row shards too: the direct exchange takes its epoch
+ * from device memory, RCCL all-reduces are captured with the kernels around them; only the host-staged
+ * exchange (cdh_set_host_exchange) is launched node by node. */
 int32_t cdh_set_use_graph(cdh_handle h, int32_t on);
 /* Multi-process row sharding: rank 0 calls cdh_comm_unique_id, broadcasts the
  * 128 bytes (any transport), every rank calls cdh_comm_init. */
@@ -208,6 +218,20 @@ int32_t cdh_p2p_local_handle(cdh_handle h, void *out_64_bytes);
 int32_t cdh_p2p_connect(cdh_handle h, const void *handles_64_bytes_each, int32_t rank, int32_t nranks);
 int32_t cdh_p2p_enable(cdh_handle h, int32_t on);
 int32_t cdh_exchange_probe(cdh_handle h, double *inout, int64_t count);
+/* Bring-your-own transport for the row-shard exchange (MPI.jl from the Julia side, gloo in this
+ * repository's tests): `fn` must sum `count` doubles in place over all ranks and return 0.  The library
+ * stages the record through pinned host memory and calls it on the caller's thread in the middle of
+ * the sweep, between the reduce and the scalar-update kernels -- the same seam the RCCL all-reduce and
+ * the direct exchange sit behind.  Slower than both (a stream round trip per exchange); fn == NULL
+ * removes it. */
+typedef int32_t (*cdh_host_allreduce_fn)(void *user, double *inout, int64_t count);
+int32_t cdh_set_host_exchange(cdh_handle h, cdh_host_allreduce_fn fn, void *user, int32_t rank,
+                              int32_t nranks);
+/* How many all-reduces this handle has issued through each exchange since it was created, and the
+ * rank count the active exchange reports (ncclCommCount for RCCL; 1 when the handle is not sharded).
+ * Any out pointer may be NULL. */
+int32_t cdh_exchange_stats(cdh_handle h, int64_t *out_rccl_calls, int64_t *out_p2p_calls,
+                           int64_t *out_host_calls, int32_t *out_nranks);
 /* Average time (microseconds, HIP events on the handle's stream) of `iters` back-to-back all-reduces
  * of `count` (<= 4096) doubles through the active exchange; 0-ish when the handle is not sharded.
  * Collective: every rank calls it with the same arguments. */

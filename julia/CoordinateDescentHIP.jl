@@ -1,21 +1,37 @@
-# CoordinateDescentHIP.jl -- the binding a CoordinateDescent.jl maintainer would add to route
-# coordinateDescent! for CDLeastSquaresLoss / CDSqrtLassoLoss through libcdhip.so (include/cdhip.h).
+# CoordinateDescentHIP.jl -- the binding a CoordinateDescent.jl maintainer would add to route the
+# coordinate-descent path through libcdhip.so (include/cdhip.h) for a design matrix that lives in HBM.
 #
 # NOT EXECUTED in this repository's pipeline: there is no `julia` in the build image or on the GPU
-# box.  It is deliberately a thin ccall shim with no arithmetic: every number comes from the
-# library.  lasso(), sqrtLasso(), scaledLasso!, LassoPath, CDOptions, ProxL1 and SparseIterate
-# are untouched; only the methods below are added (more specific than the generic ones in
-# src/coordinate_descent.jl and src/cd_differentiable_function.jl).
+# box.  It is deliberately a thin ccall shim with no arithmetic beyond an s x s solve: every number
+# comes from the library.  tests/test_binding_call_sequence.py replays, with plain ctypes and nothing
+# else in between, the exact sequence of C calls each method below makes (function by function) and
+# checks the results against the oracle -- that is the executable evidence for this file.
+#
+# lasso(), sqrtLasso(), scaledLasso!, LassoPath, CDOptions, IterLassoOptions, ProxL1, SparseIterate and
+# the loss constructors are untouched: the user passes a HipMatrix where a Matrix went, and multiple
+# dispatch picks the methods below (each strictly more specific than the reference's generic one).
+#
+#   front-end (src/lasso.jl)              methods of this file it ends up in
+#   lasso(X, y, λ[, ω])        :26-53     coordinateDescent!
+#   sqrtLasso(X, y, λ, ω)      :84-98     coordinateDescent!      (standardizeX=true is dead code in the
+#   sqrtLasso(...; standardizeX=false)                             reference itself: `Array{T}(p)`, :73)
+#   scaledLasso!(x, X, y, λ, ω) :107-144  _findInitResiduals! (:Screening), initialize! (:WarmStart),
+#                                         coordinateDescent! per σ iteration
+#   LassoPath(X, Y, λpath)     :229-260   _stdX!, coordinateDescent! per λ
 module CoordinateDescentHIP
 
 using CoordinateDescent, ProximalBase
+using LinearAlgebra: Symmetric
 using SparseArrays: nnz
+using DataStructures: nlargest
 import CoordinateDescent: coordinateDescent!, initialize!, gradient, descendCoordinate!,
-                          numCoordinates, CDOptions, CDLeastSquaresLoss, CDSqrtLassoLoss
+                          numCoordinates, CDOptions, CDLeastSquaresLoss, CDSqrtLassoLoss, CDWeightedLSLoss,
+                          _stdX!, _findInitResiduals!, _findLargestCorrelations
 
 const libcdhip = get(ENV, "LIBCDHIP", "libcdhip.so")
 
 const CDH_OK, CDH_DIM_MISMATCH, CDH_BAD_ARG, CDH_DOMAIN = Int32(0), Int32(1), Int32(2), Int32(3)
+const CDH_LS, CDH_SQRT, CDH_WLS = Int32(0), Int32(1), Int32(2)
 
 struct CdhOptions            # cdh_options: CDOptions field for field (src/utils.jl:7-13) + seed
   maxIter::Int64
@@ -43,12 +59,15 @@ function check(h::Ptr{Cvoid}, st::Int32)
 end
 
 # A matrix whose columns live in HBM behind a cdh handle.  <: DenseMatrix so it satisfies
-# lasso(X::StridedMatrix{T}, ...) (src/lasso.jl:27); getindex is for display only.
+# lasso(X::StridedMatrix{T}, ...) (src/lasso.jl:27); getindex is for display only.  The handle also
+# holds y, r (and w) of whichever loss object used it last: `owner` is the objectid of that loss's
+# residual vector (`f.r`, a fresh `copy(y)` per loss object, cd_differentiable_function.jl:54), so
+# every method below can tell whether the device-side y / loss kind are still its own.
 mutable struct HipMatrix{T<:Union{Float32,Float64}} <: DenseMatrix{T}
   handle::Ptr{Cvoid}
   n::Int
   p::Int
-  loss::Int32
+  owner::UInt
 end
 Base.size(X::HipMatrix) = (X.n, X.p)
 Base.getindex(X::HipMatrix{T}, i::Int, j::Int) where {T} = begin
@@ -61,29 +80,61 @@ end
 dtype_code(::Type{Float64}) = Int32(0)
 dtype_code(::Type{Float32}) = Int32(1)
 
-"Upload a host matrix and response; `loss` is 0 (LS) or 1 (SQRT).  Replaces the loss constructors'
-`r = copy(y)` (src/cd_differentiable_function.jl:52-55, 211-214)."
-function HipMatrix(X::StridedMatrix{T}, y::StridedVector{T}; loss::Integer=0, device::Integer=0) where {T}
+"Upload a host matrix once; every later lasso / sqrtLasso / scaledLasso! / LassoPath call on it runs in HBM."
+function HipMatrix(X::StridedMatrix{T}; device::Integer=0) where {T}
   n, p = size(X)
-  length(y) == n || throw(DimensionMismatch())
   ref = Ref{Ptr{Cvoid}}(C_NULL)
   check(C_NULL, ccall((:cdh_create, libcdhip), Int32,
                       (Ref{Ptr{Cvoid}}, Int32, Int32, Int64, Int64, Int64, Int64, Int32),
-                      ref, dtype_code(T), loss, n, n, 0, p, device))
+                      ref, dtype_code(T), CDH_LS, n, n, 0, p, device))
   h = ref[]
-  GC.@preserve X y begin
-    check(h, ccall((:cdh_set_X_cols, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64),
-                   h, 0, p, X, stride(X, 2)))
-    check(h, ccall((:cdh_set_y, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), h, y))
-  end
-  M = HipMatrix{T}(h, n, p, Int32(loss))
+  GC.@preserve X check(h, ccall((:cdh_set_X_cols, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64),
+                                h, 0, p, X, stride(X, 2)))
+  M = HipMatrix{T}(h, n, p, UInt(0))
   finalizer(m -> ccall((:cdh_destroy, libcdhip), Int32, (Ptr{Cvoid},), m.handle), M)
   M
 end
 
 const HipLS{T}   = CDLeastSquaresLoss{T,<:Any,<:HipMatrix{T}}
 const HipSqrt{T} = CDSqrtLassoLoss{T,<:Any,<:HipMatrix{T}}
-const HipLoss{T} = Union{HipLS{T},HipSqrt{T}}
+const HipWLS{T}  = CDWeightedLSLoss{T,<:Any,<:HipMatrix{T}}
+const HipLoss{T} = Union{HipLS{T},HipSqrt{T},HipWLS{T}}
+
+loss_kind(::HipLS) = CDH_LS
+loss_kind(::HipSqrt) = CDH_SQRT
+loss_kind(::HipWLS) = CDH_WLS
+
+set_loss!(X::HipMatrix, kind::Int32) =
+  check(X.handle, ccall((:cdh_set_loss, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, kind))
+
+function upload_y!(X::HipMatrix{T}, y::AbstractVector{T}) where {T}
+  length(y) == X.n || throw(DimensionMismatch())
+  yy = y isa Vector{T} ? y : Vector{T}(y)            # contiguous host copy of a view / range
+  GC.@preserve yy check(X.handle, ccall((:cdh_set_y, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), X.handle, yy))
+end
+
+"Make the handle serve THIS loss object: its kind (the Julia type decides, never a flag given at upload
+time), its y (and w).  A loss object is bound when first used and re-bound whenever another loss used
+the same HipMatrix in between -- `lasso(Xh, y2, λ)` after `lasso(Xh, y1, λ)` solves against y2, and a
+CDSqrtLassoLoss never runs the least-squares update.  (y mutated in place under a live loss object is
+the one thing this cannot see: call `rebind!(f)`.)"
+function bind!(f::HipLoss{T}) where {T}
+  X = f.X
+  X.owner == objectid(f.r) && return f
+  rebind!(f)
+end
+function rebind!(f::HipLoss{T}) where {T}
+  X = f.X
+  set_loss!(X, loss_kind(f))
+  upload_y!(X, f.y)                                   # also r = copy(y), as the loss constructors do
+  if f isa HipWLS
+    w = f.w isa Vector{T} ? f.w : Vector{T}(f.w)
+    length(w) == X.n || throw(DimensionMismatch())
+    GC.@preserve w check(X.handle, ccall((:cdh_set_obs_weights, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), X.handle, w))
+  end
+  X.owner = objectid(f.r)
+  f
+end
 
 numCoordinates(f::HipLoss) = f.X.p
 
@@ -100,6 +151,10 @@ function push_iterate!(f::HipLoss, x::SparseIterate, rebuild::Bool)
   end
 end
 
+"callers read f.r afterwards (src/lasso.jl:37,134,143): one device -> host copy"
+pull_residual!(f::HipLoss) =
+  check(f.X.handle, ccall((:cdh_get_residual, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), f.X.handle, f.r))
+
 function pull_iterate!(f::HipLoss{T}, x::SparseIterate{T}) where {T}
   p = f.X.p
   idx = Vector{Int64}(undef, p); nz = Ref{Int64}(0); beta = Vector{Float64}(undef, p)
@@ -109,8 +164,7 @@ function pull_iterate!(f::HipLoss{T}, x::SparseIterate{T}) where {T}
   for i in 1:nz[]                       # re-insert in the library's support order
     x[idx[i]] = T(beta[idx[i]])
   end
-  # callers read f.r afterwards (src/lasso.jl:37): one device -> host copy per solve
-  check(f.X.handle, ccall((:cdh_get_residual, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), f.X.handle, f.r))
+  pull_residual!(f)
   x
 end
 
@@ -122,17 +176,20 @@ function set_penalty!(f::HipLoss, g::ProxL1)
 end
 
 # ---- the four-function operator interface (src/cd_differentiable_function.jl:1-35) ----------
-initialize!(f::HipLoss, x::SparseIterate) = (push_iterate!(f, x, true); nothing)
+function initialize!(f::HipLoss{T}, x::SparseIterate{T}) where {T}
+  bind!(f); push_iterate!(f, x, true); pull_residual!(f)   # scaledLasso! :WarmStart reads std(f.r) next (:125-126)
+  nothing
+end
 
 function gradient(f::HipLoss{T}, x::SparseIterate{T}, k::Int64) where {T}
-  push_iterate!(f, x, false)
+  bind!(f); push_iterate!(f, x, false)
   out = Ref{Float64}(0)
   check(f.X.handle, ccall((:cdh_gradient, libcdhip), Int32, (Ptr{Cvoid}, Int64, Ref{Float64}), f.X.handle, k, out))
   T(out[])
 end
 
 function descendCoordinate!(f::HipLoss{T}, g::ProxL1{T}, x::SparseIterate{T}, k::Int64) where {T}
-  set_penalty!(f, g); push_iterate!(f, x, false)
+  bind!(f); set_penalty!(f, g); push_iterate!(f, x, false)
   out = Ref{Float64}(0)
   check(f.X.handle, ccall((:cdh_descend, libcdhip), Int32, (Ptr{Cvoid}, Int64, Ref{Float64}), f.X.handle, k, out))
   pull_iterate!(f, x)
@@ -142,6 +199,7 @@ end
 # ---- the performance path: one ccall per solve (src/coordinate_descent.jl:7-39) ---------------
 function coordinateDescent!(x::SparseIterate{T}, f::HipLoss{T}, g::ProxL1, options::CDOptions=CDOptions()) where {T}
   ProximalBase.numCoordinates(x) == numCoordinates(f) || throw(DimensionMismatch())
+  bind!(f)
   set_penalty!(f, g)                  # checks length(g.λ) == p (coordinate_descent.jl:14-16)
   push_iterate!(f, x, false)
   opt = Ref(CdhOptions(options)); st = CdhStats()
@@ -152,12 +210,66 @@ function coordinateDescent!(x::SparseIterate{T}, f::HipLoss{T}, g::ProxL1, optio
   pull_iterate!(f, x)
 end
 
-# Optional knobs (no reference counterpart): blocked sweep width, screened full passes, reuse of
-# the carried residual by warm starts (what LassoPath wants: src/lasso.jl:250-252).
+# ---- the dense helpers the front-ends call on X itself (src/utils.jl) ---------------------------
+# Without these, LassoPath(standardizeX=true) and scaledLasso!(:Screening) would fall into the
+# reference's generic loops over X[i, j] (a device round trip per element) and into BLAS / `\\` on a
+# matrix that has no host memory.
+
+"_stdX!(out, X) (utils.jl:127-138): out[j] = sqrt(sum_i X[i,j]^2 / n), one pass over X in HBM."
+function _stdX!(out::Vector{T}, X::HipMatrix{T}) where {T<:AbstractFloat}
+  length(out) == X.p || throw(DimensionMismatch())
+  buf = Vector{Float64}(undef, X.p)
+  check(X.handle, ccall((:cdh_col_rms, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Float64}), X.handle, buf))
+  out .= T.(buf)
+  out
+end
+
+"X'y for every column (the `mul!(storage, transpose(X), y)` of utils.jl:103): y goes to the device, r = y."
+function xt_y(X::HipMatrix{T}, y::AbstractVector{T}) where {T}
+  set_loss!(X, CDH_LS)
+  upload_y!(X, y)
+  X.owner = UInt(0)                    # whatever loss was bound has lost its y: it re-binds on its next call
+  check(X.handle, ccall((:cdh_initialize, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
+                        X.handle, X.p, 0, C_NULL, C_NULL))
+  out = Vector{Float64}(undef, X.p)
+  check(X.handle, ccall((:cdh_xt_r, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Float64}), X.handle, out))
+  out
+end
+
+"_findLargestCorrelations(X, y, s) (utils.jl:96-106): BitVector of the columns with |X_j'y| >= the s-th largest."
+function _findLargestCorrelations(X::HipMatrix{T}, y::AbstractVector{T}, s::Int) where {T<:AbstractFloat}
+  storage = abs.(xt_y(X, y))
+  storage .>= nlargest(s, storage)[end]
+end
+
+"_findInitResiduals!(X, y, s, storage) (utils.jl:65-77): storage = y - Xs (Xs \\ y).  Xs \\ y is taken
+through the s x s normal equations, whose entries (Xs'Xs, Xs'y) come from one pass over the s columns
+(cdh_gram); the residual is formed on the device by initialize! with the coefficients as the iterate."
+function _findInitResiduals!(X::HipMatrix{T}, y::AbstractVector{T}, s::Int, storage::Vector{T}) where {T<:AbstractFloat}
+  S = _findLargestCorrelations(X, y, s)             # leaves y on the device and r = y
+  idx = Int64.(findall(S)); m = length(idx)
+  m <= 64 || throw(ArgumentError("screening set larger than 64 columns"))
+  G = Matrix{Float64}(undef, m, m); c = Vector{Float64}(undef, m)
+  check(X.handle, ccall((:cdh_gram, libcdhip), Int32,
+                        (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                        X.handle, m, idx, G, c, C_NULL))
+  coef = Symmetric(G) \ c
+  check(X.handle, ccall((:cdh_initialize, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
+                        X.handle, X.p, m, idx, coef))
+  check(X.handle, ccall((:cdh_get_residual, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), X.handle, storage))
+  storage
+end
+# _findInitSigma!(X, y, s, storage) = std(_findInitResiduals!(X, y, s, storage)) (utils.jl:60-64) is
+# generic and lands in the method above.
+
+# Optional knobs (no reference counterpart): blocked sweep width, screened full passes, hipGraph
+# replay, reuse of the carried residual by warm starts (what LassoPath wants: src/lasso.jl:250-252).
 set_sweep_mode!(X::HipMatrix, blocked::Bool, block::Integer=32) =
   check(X.handle, ccall((:cdh_set_sweep_mode, libcdhip), Int32, (Ptr{Cvoid}, Int32, Int32), X.handle, blocked ? 1 : 0, block))
-set_screening!(X::HipMatrix, on::Bool) =
-  check(X.handle, ccall((:cdh_set_screening, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, on ? 1 : 0))
+set_screening!(X::HipMatrix, level::Integer) =
+  check(X.handle, ccall((:cdh_set_screening, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, level))
+set_use_graph!(X::HipMatrix, on::Bool) =
+  check(X.handle, ccall((:cdh_set_use_graph, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, on ? 1 : 0))
 set_reuse_residual!(X::HipMatrix, on::Bool) =
   check(X.handle, ccall((:cdh_set_reuse_residual, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, on ? 1 : 0))
 

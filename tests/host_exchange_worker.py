@@ -1,0 +1,95 @@
+"""Worker of test_gpu_parity.py::test_sharded_launch_sequence_over_host_exchange (run under
+torch.distributed.run, every rank on cuda:0).  Each rank holds a row shard of the same problem and
+the ONLY exchange is the host-staged one (cdh_set_host_exchange -> a gloo all-reduce): no RCCL (it
+refuses two ranks on one device), no IPC inboxes.  So what runs here is the library's own sharded
+launch sequence -- k_finalize<false> -> allreduce() -> k_scalar_update, k_block_finalize<B,false> ->
+allreduce() -> k_block_scalar, k_gram_reduce -> allreduce() -> k_gram_scalar, the 2p-long column-dot
+records of _findLambdaMax / _stdX!, the moments of sigma -- with a real multi-rank sum behind the
+seam, checked against the oracle's unsharded solve.  Prints HOSTX_OK from rank 0."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import coordinatedescent_jl_amd as cd  # noqa: E402
+from coordinatedescent_jl_amd import sharded  # noqa: E402
+import oracle as O  # noqa: E402  (the checker)
+
+
+def main():
+    cp = sharded.ControlPlane(backend="gloo")
+    assert cp.world >= 2
+    n, p = 20011, 70
+    rng = np.random.default_rng(23)
+    X = np.asfortranarray(rng.standard_normal((n, p)))
+    y = X[:, :9] @ (2 * rng.standard_normal(9)) + rng.standard_normal(n)
+    w = rng.uniform(0.5, 2.0, size=n)
+    om = 0.5 + rng.random(p)
+    row0, nl = sharded.shard_rows(n, cp.rank, cp.world)
+    rows = slice(row0, row0 + nl)
+    o = dict(randomize=False, optTol=1e-11, maxIter=800)
+
+    def shard(cls, *extra):
+        f = cls(y[rows], X[rows], *[e[rows] for e in extra], device=0, n_total=n, row_offset=row0)
+        sharded.connect_host(f, cp)
+        return f
+
+    def same_on_all_ranks(v):
+        every = np.frombuffer(cp.all_gather_bytes(np.ascontiguousarray(v).tobytes()), dtype=np.float64).reshape(cp.world, -1)
+        return all(np.array_equal(every[0], every[q]) for q in range(1, cp.world))
+
+    cases = [("ls", "coord", 0, 0.05, None), ("ls", "block", 8, 0.05, om), ("ls", "block", 16, 0.05, None),
+             ("ls", "block", 32, 0.03, om), ("ls", "block", 64, 0.05, None),
+             ("sqrt", "coord", 0, 3.5, om), ("sqrt", "block", 8, 3.5, None), ("sqrt", "block", 32, 3.5, om),
+             ("wls", "coord", 0, 0.05, None), ("wls", "block", 16, 0.05, om)]
+    for loss, mode, block, lam, omega in cases:
+        if loss == "ls":
+            f, fo = shard(cd.CDLeastSquaresLoss), O.CDLeastSquaresLoss(y, X)
+        elif loss == "sqrt":
+            f, fo = shard(cd.CDSqrtLassoLoss), O.CDSqrtLassoLoss(y, X)
+        else:
+            f, fo = shard(cd.CDWeightedLSLoss, w), O.CDWeightedLSLoss(y, X, w)
+        f.set_sweep_mode(mode, block or 8)
+        f.set_use_graph(True)       # the host-staged exchange is never recorded: node-by-node launches
+        for warm in (True, False):  # the cold start adds _findLambdaMax: a 2p-long record through the seam
+            x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+            before = f.exchange_stats()["host_calls"]
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam, omega), cd.CDOptions(warmStart=warm, **o))
+            st = O.coordinateDescent_(xo, fo, O.ProxL1(lam, omega), O.CDOptions(warmStart=warm, **o))
+            err = float(np.max(np.abs(x.dense() - xo.dense())))
+            assert err < 1e-10, (loss, mode, block, warm, err)
+            assert sorted(x.nzval2ind.tolist()) == sorted(xo.nzval2ind.tolist()), (loss, mode, block, warm)
+            if mode == "coord":     # same visit order, support order and pass count as the reference state machine
+                assert x.nzval2ind.tolist() == xo.nzval2ind.tolist(), (loss, warm)
+                assert f.last_stats["passes"] == st["passes"], (loss, warm)
+            assert same_on_all_ranks(x.dense()), "ranks disagree"
+            es = f.exchange_stats()
+            assert es["host_calls"] > before and es["rccl_calls"] == 0 and es["p2p_calls"] == 0 and es["nranks"] == cp.world
+        np.testing.assert_allclose(cd.objective(f), O.objective(fo, O.ProxL1(lam, omega), xo), rtol=1e-12)
+        np.testing.assert_allclose(f.r, fo.r[rows], rtol=0, atol=1e-9)       # each rank holds its own residual rows
+        np.testing.assert_allclose(cd.stdX(f), O.stdX(X), rtol=1e-13)        # _stdX! over all shards
+        cp.barrier()
+        f.close()
+
+    # scaledLasso! on shards: the :Screening init (X'y scores, the s x s normal equations through cdh_gram,
+    # std of the OLS residuals) and the sigma loop all go through the seam
+    f = shard(cd.CDLeastSquaresLoss)
+    f.set_sweep_mode("block", 32)
+    x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+    io = dict(maxIter=50, optTol=1e-6)
+    sol = cd.scaledLasso_(x, f, None, 0.08, om, cd.IterLassoOptions(optionsCD=cd.CDOptions(**o), **io))
+    so = O.scaledLasso_(xo, X, y, 0.08, om, O.IterLassoOptions(optionsCD=O.CDOptions(**o), **io))
+    np.testing.assert_allclose(sol.sigma, so.sigma, rtol=1e-9)
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-9)
+    assert same_on_all_ranks(x.dense())
+    cp.barrier()
+    f.close()
+    if cp.rank == 0:
+        print("HOSTX_OK")
+    cp.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,20 @@ def main():
         lm = cd.findLambdaMax(cd.SparseIterate(p), f, cd.ProxL1(1.0))
         lo = oracle.findLambdaMax(oracle.SparseIterate(p), fo, oracle.ProxL1(1.0))
         assert abs(lm - lo) < 1e-12 * max(1.0, lo), (lm, lo)
+        # the same solve replayed from captured hipGraphs: the exchange kernels are graph nodes that take
+        # their epoch from device memory (set before each replay) -- bit-identical to node-by-node launches
+        f.set_use_graph(True)
+        xg = cd.SparseIterate(p)
+        calls0 = f.exchange_stats()["p2p_calls"]
+        cd.coordinateDescent_(xg, f, cd.ProxL1(lam), opt)
+        assert np.array_equal(xg.dense(), got), ("graph replay differs", mode, block)
+        assert f.exchange_stats()["p2p_calls"] > calls0
+        xg = cd.SparseIterate(p)
+        cd.coordinateDescent_(xg, f, cd.ProxL1(0.5 * lam), opt)      # warm graphs of the same lengths, new epochs
+        f.set_use_graph(False)
+        xn = cd.SparseIterate(p)
+        cd.coordinateDescent_(xn, f, cd.ProxL1(0.5 * lam), opt)
+        assert np.array_equal(xg.dense(), xn.dense()), ("graph replay differs at the second lambda", mode, block)
         # longer than one inbox slot and no communicator: chunked through the same inboxes
         v = np.arange(4096, dtype=np.float64) * (1 + cp.rank)
         assert np.array_equal(f.exchange_probe(v), (cp.world * (cp.world + 1) / 2) * np.arange(4096, dtype=np.float64))

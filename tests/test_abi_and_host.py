@@ -108,3 +108,34 @@ def test_sparse_iterate_matches_oracle_bookkeeping():
     y = x.copy()
     x.fill_(0.0)
     assert x.nnz == 0 and y.nnz == xo.nnz and y == y.copy() and not (y == x)
+
+
+def test_every_export_rejects_a_null_handle():
+    """status codes, never an abort.  Every entry point that takes a handle returns
+    CDH_BAD_ARG for NULL (cdh_destroy(NULL) is a no-op, cdh_last_error(NULL) is the create error);
+    nothing here touches a device, so it runs without a GPU."""
+    L = cd._lib.lib()
+    BAD = cd._lib.CDH_BAD_ARG
+    no_handle = {"cdh_create", "cdh_destroy", "cdh_last_error", "cdh_device_count", "cdh_comm_unique_id"}
+    checked = 0
+    for name in cd.declared_symbols():
+        if name in no_handle:
+            continue
+        fn = getattr(L, name)
+        args = [None]
+        for t in fn.argtypes[1:]:
+            if t in (C.c_int32, C.c_int64, C.c_uint64):
+                args.append(0)
+            elif t is C.c_double:
+                args.append(0.0)
+            elif t is cd._lib.HOST_ALLREDUCE_FN:
+                args.append(cd._lib.HOST_ALLREDUCE_FN(0))
+            else:
+                args.append(None)
+        assert fn(*args) == BAD, name
+        assert b"NULL" in L.cdh_last_error(None), name
+        checked += 1
+    assert checked >= 38
+    assert L.cdh_destroy(None) == cd._lib.CDH_OK
+    assert L.cdh_device_count(None) == BAD and L.cdh_comm_unique_id(None) == BAD
+    assert L.cdh_create(None, 0, 0, 8, 8, 0, 2, 0) == BAD

@@ -1,0 +1,401 @@
+"""The Julia binding (julia/CoordinateDescentHIP.jl) cannot be executed in this pipeline (no `julia` in
+the image), so this file REPLAYS it: every method of the binding is restated below as the exact
+sequence of C-ABI calls it makes -- plain ctypes on libcdhip.so, none of coordinatedescent.jl_amd/api.py
+in between -- and the reference's front-ends (src/lasso.jl) are driven on top of those methods in the
+order lasso.jl calls them.  Results are compared with the oracle.  What this proves: the C entry
+points, called the way the binding calls them, are sufficient and correct for lasso, sqrtLasso,
+scaledLasso! (:Screening and :WarmStart), LassoPath (standardizeX) and CDWeightedLSLoss, including the
+cases round 1's binding got wrong (a second y on the same matrix, a sqrt-lasso loss on a handle
+created for least squares, two live loss objects on one matrix).
+
+Each replayed method names the binding function it mirrors; keep the two in step.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.environ.get("CDHIP_SO") or os.path.join(ROOT, "coordinatedescent.jl_amd", "csrc", "libcdhip.so")
+CDH_LS, CDH_SQRT, CDH_WLS = 0, 1, 2
+
+
+class CdhOptions(C.Structure):       # struct CdhOptions of the binding
+    _fields_ = [("maxIter", C.c_int64), ("optTol", C.c_double), ("randomize", C.c_int32),
+                ("warmStart", C.c_int32), ("numSteps", C.c_int64), ("seed", C.c_uint64)]
+
+
+class CdhStats(C.Structure):         # mutable struct CdhStats of the binding
+    _fields_ = [("passes", C.c_int64), ("full_passes", C.c_int64), ("visits", C.c_int64),
+                ("converged", C.c_int32), ("domain_error", C.c_int32), ("maxH", C.c_double),
+                ("lambda_max", C.c_double)]
+
+
+class DimensionMismatch(Exception):
+    pass
+
+
+class ArgumentError(Exception):
+    pass
+
+
+_L = None
+
+
+def lib():
+    global _L
+    if _L is None:
+        _L = C.CDLL(SO)
+        _L.cdh_last_error.restype = C.c_char_p
+        _L.cdh_last_error.argtypes = [C.c_void_p]
+    return _L
+
+
+def ccall(name, h, *args):
+    """ccall((name, libcdhip), Int32, ...) followed by the binding's check(h, st)."""
+    st = getattr(lib(), name)(h, *args)
+    if st == 0:
+        return
+    msg = (lib().cdh_last_error(h) or b"").decode()
+    if st == 1:
+        raise DimensionMismatch(msg)
+    if st == 2:
+        raise ArgumentError(msg)
+    raise RuntimeError(f"cdhip status {st}: {msg}")
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+i64, i32, f64 = C.c_int64, C.c_int32, C.c_double
+
+
+# ---- the binding's types --------------------------------------------------------------------------
+class HipMatrix:
+    """mutable struct HipMatrix + HipMatrix(X; device): cdh_create(LS) + cdh_set_X_cols, nothing about y."""
+
+    def __init__(self, X):
+        X = np.asfortranarray(X)
+        self.n, self.p = X.shape
+        self.dtype = X.dtype
+        h = C.c_void_p()
+        st = lib().cdh_create(C.byref(h), i32(0 if X.dtype == np.float64 else 1), i32(CDH_LS), i64(self.n),
+                              i64(self.n), i64(0), i64(self.p), i32(0))
+        assert st == 0, lib().cdh_last_error(None)
+        self.handle = h
+        ccall("cdh_set_X_cols", h, i64(0), i64(self.p), ptr(X), i64(X.strides[1] // X.itemsize))
+        self.owner = 0
+
+    def close(self):
+        lib().cdh_destroy(self.handle)
+
+
+class Loss:
+    """What the reference's loss constructors build (cd_differentiable_function.jl:52-55, 128-131, 211-214):
+    y, X, (w,) r = copy(y).  kind is the Julia TYPE of the loss, not a flag on the matrix."""
+
+    def __init__(self, kind, y, X, w=None):
+        if len(y) != X.n or (w is not None and len(w) != X.n):
+            raise DimensionMismatch()
+        self.kind, self.y, self.X, self.w, self.r = kind, y, X, w, y.copy()
+
+
+class SparseIterate:
+    """ProximalBase's iterate as far as the binding touches it: nzval2ind / nzval in insertion order."""
+
+    def __init__(self, p):
+        self.p, self.idx, self.val = p, [], []
+
+    def dense(self):
+        out = np.zeros(self.p)
+        out[np.asarray(self.idx, dtype=np.int64) - 1] = self.val
+        return out
+
+
+# ---- the binding's methods, call for call ---------------------------------------------------------
+def rebind(f):                       # rebind!(f)
+    X = f.X
+    ccall("cdh_set_loss", X.handle, i32(f.kind))
+    yy = np.ascontiguousarray(f.y, dtype=X.dtype)
+    ccall("cdh_set_y", X.handle, ptr(yy))
+    if f.kind == CDH_WLS:
+        ww = np.ascontiguousarray(f.w, dtype=X.dtype)
+        ccall("cdh_set_obs_weights", X.handle, ptr(ww))
+    X.owner = id(f.r)                # objectid(f.r)
+
+
+def bind(f):                         # bind!(f)
+    if f.X.owner != id(f.r):
+        rebind(f)
+
+
+def push_iterate(f, x, rebuild):     # push_iterate!(f, x, rebuild)
+    idx = np.ascontiguousarray(x.idx, dtype=np.int64)
+    val = np.ascontiguousarray(x.val, dtype=np.float64)
+    ccall("cdh_initialize" if rebuild else "cdh_set_iterate", f.X.handle, i64(x.p), i64(len(idx)),
+          ptr(idx) if len(idx) else None, ptr(val) if len(idx) else None)
+
+
+def pull_residual(f):                # pull_residual!(f)
+    ccall("cdh_get_residual", f.X.handle, ptr(f.r))
+
+
+def pull_iterate(f, x):              # pull_iterate!(f, x)
+    p = f.X.p
+    idx, nz, beta = np.zeros(p, dtype=np.int64), i64(0), np.zeros(p)
+    ccall("cdh_get_support", f.X.handle, ptr(idx), C.byref(nz))
+    ccall("cdh_get_beta", f.X.handle, ptr(beta))
+    x.idx = idx[: nz.value].tolist()
+    x.val = [float(beta[k - 1]) for k in x.idx]
+    pull_residual(f)
+    return x
+
+
+def set_penalty(f, lam0, omega):     # set_penalty!(f, g)
+    om = None if omega is None else np.ascontiguousarray(omega, dtype=np.float64)
+    ccall("cdh_set_penalty", f.X.handle, f64(lam0), None if om is None else ptr(om), i64(0 if om is None else len(om)))
+
+
+def initialize(f, x):                # initialize!(f, x)
+    bind(f)
+    push_iterate(f, x, True)
+    pull_residual(f)
+
+
+def coordinateDescent(x, f, lam0, omega, opt):     # coordinateDescent!(x, f, g, options)
+    if x.p != f.X.p:
+        raise DimensionMismatch()
+    bind(f)
+    set_penalty(f, lam0, omega)
+    push_iterate(f, x, False)
+    o = CdhOptions(opt["maxIter"], opt["optTol"], int(opt["randomize"]), int(opt.get("warmStart", True)),
+                   opt.get("numSteps", 50), opt.get("seed", 0))
+    st = CdhStats()
+    ccall("cdh_coordinate_descent", f.X.handle, C.byref(o), C.byref(st))
+    assert st.domain_error == 0
+    pull_iterate(f, x)
+    return st
+
+
+def stdX(X):                         # _stdX!(out, X::HipMatrix)
+    buf = np.zeros(X.p)
+    ccall("cdh_col_rms", X.handle, ptr(buf))
+    return buf.astype(X.dtype)
+
+
+def xt_y(X, y):                      # xt_y(X, y)
+    ccall("cdh_set_loss", X.handle, i32(CDH_LS))
+    yy = np.ascontiguousarray(y, dtype=X.dtype)
+    ccall("cdh_set_y", X.handle, ptr(yy))
+    X.owner = 0
+    ccall("cdh_initialize", X.handle, i64(X.p), i64(0), None, None)
+    out = np.zeros(X.p)
+    ccall("cdh_xt_r", X.handle, ptr(out))
+    return out
+
+
+def findLargestCorrelations(X, y, s):            # _findLargestCorrelations(X::HipMatrix, y, s)
+    storage = np.abs(xt_y(X, y))
+    return storage >= np.sort(storage)[::-1][s - 1]
+
+
+def findInitResiduals(X, y, s, storage):         # _findInitResiduals!(X::HipMatrix, y, s, storage)
+    S = findLargestCorrelations(X, y, s)
+    idx = np.ascontiguousarray(np.nonzero(S)[0] + 1, dtype=np.int64)
+    m = len(idx)
+    assert m <= 64
+    G, c = np.zeros((m, m)), np.zeros(m)
+    ccall("cdh_gram", X.handle, i64(m), ptr(idx), ptr(G), ptr(c), None)
+    coef = np.ascontiguousarray(np.linalg.solve(G, c))
+    ccall("cdh_initialize", X.handle, i64(X.p), i64(m), ptr(idx), ptr(coef))
+    ccall("cdh_get_residual", X.handle, ptr(storage))
+    return storage
+
+
+# ---- the REFERENCE's front-ends (src/lasso.jl), untouched logic, on top of the methods above ---------
+def lasso(X, y, lam, omega=None, opt=None):                      # lasso.jl:26-53
+    x = SparseIterate(X.p)
+    f = Loss(CDH_LS, y, X)
+    coordinateDescent(x, f, lam, omega, opt)
+    return x, f.r, float(np.std(f.r, ddof=1))
+
+
+def sqrtLasso(X, y, lam, omega, opt):                            # lasso.jl:84-98
+    x = SparseIterate(X.p)
+    f = Loss(CDH_SQRT, y, X)
+    coordinateDescent(x, f, lam, omega, opt)
+    return x, f.r, float(np.std(f.r, ddof=1))
+
+
+def scaledLasso(x, X, y, lam, omega, init, sinit, sigmainit, maxIter, optTol, optCD):    # lasso.jl:107-144
+    n = X.n
+    f = Loss(CDH_LS, y, X)
+    if init == "Screening":
+        sigma = float(np.std(findInitResiduals(X, y, sinit, f.r), ddof=1))     # _findInitSigma! (utils.jl:60-64)
+    elif init == "InitStd":
+        sigma = sigmainit
+    else:
+        initialize(f, x)
+        sigma = float(np.std(f.r, ddof=1))
+    lam0 = lam * sigma
+    for _ in range(maxIter):
+        coordinateDescent(x, f, lam0, omega, optCD)
+        sigmanew = float(np.sqrt(np.sum(f.r.astype(np.float64) ** 2) / n))
+        if abs(sigmanew - sigma) / sigma < optTol:
+            break
+        sigma = sigmanew
+        lam0 = lam * sigma
+    return x, f.r, float(np.std(f.r, ddof=1))
+
+
+def LassoPath(X, Y, lams, opt, standardizeX=True):               # lasso.jl:229-260
+    sx = stdX(X) if standardizeX else np.ones(X.p, dtype=X.dtype)
+    x = SparseIterate(X.p)
+    f = Loss(CDH_LS, Y, X)
+    path = []
+    for lam in lams:
+        coordinateDescent(x, f, lam, sx, opt)
+        path.append(x.dense())
+    return path
+
+
+# ---- tests ----------------------------------------------------------------------------------------
+OPT = dict(maxIter=5000, optTol=1e-11, randomize=False)
+
+
+def _problem(seed, n, p, s, noise=1.0):
+    rng = np.random.default_rng(seed)
+    X = np.asfortranarray(rng.standard_normal((n, p)))
+    Y = X[:, :s] @ rng.standard_normal(s) + noise * rng.standard_normal(n)
+    return rng, X, Y
+
+
+def test_lasso_twice_on_one_matrix_uses_the_y_it_is_given():
+    rng, X, Y1 = _problem(1, 2000, 80, 8)
+    Y2 = X[:, 40:46] @ rng.standard_normal(6) + rng.standard_normal(2000)
+    Xh = HipMatrix(X)
+    for Y, om in ((Y1, None), (Y2, None), (Y1, rng.random(80) + 0.5)):
+        x, r, sig = lasso(Xh, Y, 0.07, om, OPT)
+        so = O.lasso(X, Y, 0.07, om, O.CDOptions(**OPT))
+        np.testing.assert_allclose(x.dense(), so.x.dense(), rtol=0, atol=1e-10)
+        np.testing.assert_allclose(r, Y - X @ x.dense(), rtol=0, atol=1e-9)      # f.r came back to the host
+        np.testing.assert_allclose(sig, so.sigma, rtol=1e-9)
+    Xh.close()
+
+
+def test_loss_kind_follows_the_julia_type_not_the_upload():
+    """A CDSqrtLassoLoss on a matrix uploaded by HipMatrix(X) (created as least squares) runs the
+    sqrt-lasso update; a least-squares loss right after it runs least squares again."""
+    rng, X, Y = _problem(2, 1500, 60, 6)
+    Xh = HipMatrix(X)
+    om = np.ones(60)
+    x, r, _ = sqrtLasso(Xh, Y, 2.5, om, OPT)
+    so = O.sqrtLasso(X, Y, 2.5, om, O.CDOptions(**OPT))
+    np.testing.assert_allclose(x.dense(), so.x.dense(), rtol=0, atol=1e-10)
+    rr = Y - X @ x.dense()
+    assert max(0.0, np.max(np.abs(X.T @ rr / np.linalg.norm(rr))) - 2.5) / 2.5 < 1e-6     # test/lasso.jl:123
+    x2, _, _ = lasso(Xh, Y, 0.05, None, OPT)
+    np.testing.assert_allclose(x2.dense(), O.lasso(X, Y, 0.05, None, O.CDOptions(**OPT)).x.dense(), rtol=0, atol=1e-10)
+    Xh.close()
+
+
+def test_two_live_losses_on_one_matrix_rebind_each_other():
+    rng, X, Y1 = _problem(3, 1200, 40, 5)
+    Y2 = X[:, 20:25] @ rng.standard_normal(5) + rng.standard_normal(1200)
+    Xh = HipMatrix(X)
+    f1, f2 = Loss(CDH_LS, Y1, Xh), Loss(CDH_SQRT, Y2, Xh)
+    x1, x2 = SparseIterate(40), SparseIterate(40)
+    for lam1, lam2 in ((0.2, 3.0), (0.05, 2.0)):         # alternate: every call finds the other loss bound
+        coordinateDescent(x1, f1, lam1, None, OPT)
+        coordinateDescent(x2, f2, lam2, None, OPT)
+    xo1, xo2 = O.SparseIterate(40), O.SparseIterate(40)
+    fo1, fo2 = O.CDLeastSquaresLoss(Y1, X), O.CDSqrtLassoLoss(Y2, X)
+    for lam1, lam2 in ((0.2, 3.0), (0.05, 2.0)):
+        O.coordinateDescent_(xo1, fo1, O.ProxL1(lam1), O.CDOptions(**OPT))
+        O.coordinateDescent_(xo2, fo2, O.ProxL1(lam2), O.CDOptions(**OPT))
+    np.testing.assert_allclose(x1.dense(), xo1.dense(), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(x2.dense(), xo2.dense(), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(f1.r, fo1.r, rtol=0, atol=1e-9)
+    Xh.close()
+
+
+@pytest.mark.parametrize("standardize", [True, False])
+def test_lasso_path_sequence(standardize):
+    rng, X, Y = _problem(4, 1000, 300, 30)
+    X *= rng.uniform(0.3, 3.0, size=300)                 # uneven column scales: stdX matters
+    Xh = HipMatrix(X)
+    lams = [0.3, 0.1, 0.03]
+    path = LassoPath(Xh, Y, lams, OPT, standardizeX=standardize)
+    np.testing.assert_allclose(stdX(Xh), np.sqrt((X * X).sum(0) / 1000), rtol=1e-13)
+    lo, bo = O.LassoPath(X, Y, lams, O.CDOptions(**OPT), standardizeX=standardize)
+    for got, want in zip(path, bo):
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
+    Xh.close()
+
+
+@pytest.mark.parametrize("init", ["Screening", "InitStd", "WarmStart"])
+def test_scaled_lasso_sequence(init):
+    rng, X, Y = _problem(5, 1000, 200, 20)
+    Xh = HipMatrix(X)
+    om = rng.random(200) + 0.5
+    x = SparseIterate(200)
+    if init == "WarmStart":
+        x.idx, x.val = [3, 1], [0.4, -0.2]
+    optCD = dict(maxIter=5000, optTol=1e-10, randomize=False)
+    xg, r, sig = scaledLasso(x, Xh, Y, 0.1, om, init, 5, 2.0, 50, 1e-6, optCD)
+    xo = O.SparseIterate(200)
+    if init == "WarmStart":
+        xo[3] = 0.4
+        xo[1] = -0.2
+    so = O.scaledLasso_(xo, X, Y, 0.1, om, O.IterLassoOptions(maxIter=50, optTol=1e-6, initProcedure=init, sinit=5,
+                                                             sigmainit=2.0, optionsCD=O.CDOptions(**optCD)))
+    np.testing.assert_allclose(sig, so.sigma, rtol=1e-8)
+    np.testing.assert_allclose(xg.dense(), xo.dense(), rtol=0, atol=1e-8)
+    if init == "Screening":      # the screening init itself against the reference's formula (utils.jl:60-77, Xs \ y)
+        c = np.abs(X.T @ Y)
+        S = c >= np.sort(c)[::-1][4]
+        coef, *_ = np.linalg.lstsq(X[:, S], Y, rcond=None)
+        storage = np.zeros(1000)
+        np.testing.assert_allclose(findInitResiduals(Xh, Y, 5, storage), Y - X[:, S] @ coef, rtol=0, atol=1e-9)
+        assert findLargestCorrelations(Xh, Y, 5).tolist() == S.tolist()
+    Xh.close()
+
+
+def test_weighted_ls_loss_sequence_and_errors():
+    rng, X, Y = _problem(6, 3000, 45, 5)
+    w = rng.random(3000) + 0.5
+    Xh = HipMatrix(X)
+    f = Loss(CDH_WLS, Y, Xh, w)
+    x = SparseIterate(45)
+    coordinateDescent(x, f, 0.05, None, OPT)
+    xo = O.SparseIterate(45)
+    fo = O.CDWeightedLSLoss(Y, X, w)
+    O.coordinateDescent_(xo, fo, O.ProxL1(0.05), O.CDOptions(**OPT))
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-9)
+    # a plain LS loss afterwards must not see the weights
+    x2, _, _ = lasso(Xh, Y, 0.05, None, OPT)
+    np.testing.assert_allclose(x2.dense(), O.lasso(X, Y, 0.05, None, O.CDOptions(**OPT)).x.dense(), rtol=0, atol=1e-10)
+    with pytest.raises(DimensionMismatch):      # length(g.λ) != p (coordinate_descent.jl:14-16), from cdh_set_penalty
+        coordinateDescent(SparseIterate(45), Loss(CDH_LS, Y, Xh), 0.1, np.ones(44), OPT)
+    with pytest.raises(DimensionMismatch):      # numCoordinates(x) != numCoordinates(f) (:13)
+        coordinateDescent(SparseIterate(44), Loss(CDH_LS, Y, Xh), 0.1, None, OPT)
+    with pytest.raises(DimensionMismatch):      # the loss constructor's own check (:53)
+        Loss(CDH_LS, Y[:-1], Xh)
+    Xh.close()
+
+
+def test_fp32_path_sequence():
+    """LassoPath is the front-end that works in Float32 in the reference (SparseIterate(T, p), quirk Q3)."""
+    rng, X, Y = _problem(7, 4000, 64, 8)
+    Xh = HipMatrix(X.astype(np.float32))
+    path = LassoPath(Xh, Y.astype(np.float32), [0.2, 0.05], dict(maxIter=500, optTol=1e-6, randomize=False))
+    lo, bo = O.LassoPath(X, Y, [0.2, 0.05], O.CDOptions(maxIter=500, optTol=1e-10, randomize=False))
+    np.testing.assert_allclose(path[1], bo[1], rtol=0, atol=2e-4)     # fp32 storage against the fp64 oracle
+    Xh.close()
