@@ -599,15 +599,18 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
 // can move.  Same iterates as visiting one by one; a full pass over a sparse iterate then reads X
 // about once, at the plain streaming rate.  A 1e-9 relative margin sends borderline coordinates
 // through the exact path.  After a hit the next `cool` visits are not screened (doubling on
-// repeated hits), so a pass in which everything moves pays for a handful of screens only.
-constexpr int kScreen = 64;
+// repeated hits), so a pass in which everything moves pays for a handful of screens only; a screen
+// that settles all of its columns doubles the next one (64 -> 1024 columns: one host round trip per
+// screen, so long quiet stretches run at the plain streaming rate of k_col_dots).
+constexpr int kScreen = 64, kScreenMax = 1024;
 
 int32_t screened_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH) {
     const int B = (h->mode == CDH_SWEEP_BLOCK) ? h->blockB : 1;
     const double lam = h->ctrl.lambda0, nt = (double)h->n_total;
     const std::vector<double>& om = h->h_omega;
-    std::vector<double> cd((size_t)(2 * kScreen));
-    int64_t pos = 0, cool = 0, cool_len = kScreen;
+    std::vector<double> cd((size_t)(2 * kScreenMax));
+    const int64_t scr_max = std::min<int64_t>({(int64_t)kScreenMax, h->p, h->cap});   // d_colout holds 2p values
+    int64_t pos = 0, cool = 0, cool_len = kScreen, scr = std::min<int64_t>(kScreen, scr_max);
     while (pos < m) {
         if (cool > 0) {   // unscreened stretch: whole Gram blocks
             const int mm = (int)std::min<int64_t>({(int64_t)h->cap, m - pos, std::max<int64_t>(cool, B)});
@@ -615,7 +618,7 @@ int32_t screened_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double*
             pos += mm; cool -= mm;
             continue;
         }
-        const int S = (int)std::min<int64_t>(kScreen, m - pos);
+        const int S = (int)std::min<int64_t>(scr, m - pos);
         std::memcpy(h->h_idx, idx0 + pos, sizeof(int64_t) * (size_t)S);
         HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)S, hipMemcpyHostToDevice, h->stream));
         CHK(col_dots(h, 0, S, h->r, false, h->d_idx));
@@ -649,8 +652,10 @@ int32_t screened_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double*
             CHK(run_chunk(h, idx0 + pos, mm, maxH));
             pos += mm;
             cool = cool_len; cool_len = std::min<int64_t>(cool_len * 2, m);
+            scr = std::min<int64_t>(kScreen, scr_max);
         } else {
             cool_len = kScreen;
+            scr = std::min<int64_t>(scr * 2, scr_max);
         }
     }
     return CDH_OK;

@@ -87,6 +87,30 @@ def main():
         assert abs(cd.objective(f) - oracle.objective(fo2, oracle.ProxL1(3.8, om), xo)) <= 1e-12 * abs(cd.objective(f))
         cp.barrier()
         del f
+    # cfg5-shaped on shards: fp32 storage, omega = _stdX!, scaledLasso! with the :Screening init, B = 32, every
+    # pass replayed from a hipGraph whose exchange nodes read their epoch from device memory -- bit-identical to
+    # node-by-node launches, and within fp32 storage tolerance of the fp64 oracle
+    lam5 = float(np.sqrt(2 * np.log(p) / n)) * 2
+    cdo = dict(randomize=False, optTol=1e-7, maxIter=2000)
+    outs = []
+    for graph in (False, True):
+        f = cd.CDLeastSquaresLoss(y[row0:row0 + nl].astype(np.float32), X[row0:row0 + nl].astype(np.float32),
+                                  device=0, n_total=n, row_offset=row0)
+        assert sharded.connect_p2p(f, cp, selftest=False)
+        f.set_sweep_mode("block", 32)
+        f.set_use_graph(graph)
+        om5 = cd.stdX(f)
+        x = cd.SparseIterate(p)
+        sol = cd.scaledLasso_(x, f, None, lam5, om5, cd.IterLassoOptions(maxIter=50, optTol=1e-6, optionsCD=cd.CDOptions(**cdo)))
+        outs.append((x.dense(), sol.sigma, f.r))
+        cp.barrier()
+        del f
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][2], outs[1][2]) and outs[0][1] == outs[1][1]
+    xo = oracle.SparseIterate(p)
+    so = oracle.scaledLasso_(xo, X, y, lam5, oracle.stdX(X),
+                             oracle.IterLassoOptions(maxIter=50, optTol=1e-6, optionsCD=oracle.CDOptions(**cdo)))
+    assert abs(outs[1][1] - so.sigma) / so.sigma < 1e-4, (outs[1][1], so.sigma)
+    assert float(np.max(np.abs(outs[1][0] - xo.dense()))) < 3e-4
     # a peer that never arrives: the wait is bounded, the call fails, and a shard whose only exchange
     # is gone refuses to continue (no silent unsharded arithmetic)
     os.environ["CDH_P2P_SPIN_LIMIT"] = "200000"
