@@ -133,6 +133,8 @@ def lib():
         "cdh_objective": [vp, P(f64)],
         "cdh_set_sweep_mode": [vp, i32, i32],
         "cdh_set_use_graph": [vp, i32],
+        "cdh_set_gradient_cache": [vp, i32],
+        "cdh_cache_stats": [vp, P(i64)],
         "cdh_set_screening": [vp, i32],
         "cdh_comm_unique_id": [vp],
         "cdh_comm_init": [vp, vp, i32, i32],

@@ -287,6 +287,16 @@ class _HipLoss(CoordinateDifferentiableFunction):
         """0 / False: never; 1 / True: full passes of the solves (default); 2: cdPass_ as well."""
         check(self._L.cdh_set_screening(self._h, int(on)), self._h)
 
+    def set_gradient_cache(self, mode=1):
+        """0 off, 1 engage after three screened full passes on the same data (default), 2 from the first."""
+        check(self._L.cdh_set_gradient_cache(self._h, int(mode)), self._h)
+
+    def cache_stats(self):
+        out = (C.c_int64 * 6)()
+        check(self._L.cdh_cache_stats(self._h, out), self._h)
+        return dict(zip(("passes", "settled_visits", "exact_visits", "reference_passes", "gram_batches", "gram_columns"),
+                        [int(v) for v in out]))
+
     def set_use_graph(self, on=True):
         check(self._L.cdh_set_use_graph(self._h, int(bool(on))), self._h)
 

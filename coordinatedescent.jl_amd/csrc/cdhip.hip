@@ -71,6 +71,33 @@ constexpr int kNcclSum = 0;
 
 }  // namespace
 
+// Gradient cache of the screened full passes (no reference counterpart; exact).  A visit of a coordinate
+// with beta_k == 0 changes nothing unless |X_k'r| exceeds its threshold, and X_k'r is known WITHOUT reading
+// X if the Gram columns G_j = X'X_j of every coordinate that moved since a reference point are at hand:
+//   X'r = g_ref - sum_j dbeta_j G_j .
+// Only the support ever moves, so a handle that keeps solving on the same X (a lambda path, the sigma loop
+// of scaledLasso!, the 51 continuation solves of a cold start) pays one pass over X for g_ref, 1.25 passes
+// per 16 Gram columns as coordinates enter the support, and after that a full pass costs its exact visits
+// only.  Same iterates as visiting one by one: a coordinate is skipped only when the exact path would have
+// left it at zero (1e-9 relative margin, as for the dots-only screens), everything else is visited by the
+// same kernels.  fp64 storage, no observation weights.
+struct GradCache {
+    int mode = 1;                   // 0 off, 1 engages after kGcEngage screened full passes, 2 from the first one
+    bool valid = false;             // g (with the pending dbeta) describes X'r of the device's current r
+    bool beta_ok = false;           // r == y - X beta_ref up to rounding
+    int64_t full_seen = 0;          // screened full passes since the data last changed
+    int cooldown = 0, backoff = 1;  // after a busy pass: this many full passes run the plain way
+    std::vector<double> g, a, dbeta, beta_ref;
+    std::vector<int64_t> moved;     // coordinates with dbeta != 0, each once
+    std::vector<uint8_t> in_moved;
+    std::vector<int32_t> slot;      // coordinate -> Gram column, -1 = not cached
+    std::vector<std::vector<double>> G;
+    double* d_cross = nullptr;      // device: ceil(p / 64) records of 1024 cross products
+    int64_t* d_cols = nullptr;      // device: 0 .. p-1 (A operand lists) followed by the 16 B columns of a batch
+    std::vector<double> h_cross;
+    int64_t n_validate = 0, n_batches = 0, n_columns = 0, n_certified = 0, n_exact = 0, n_passes = 0;
+};
+
 struct cdh_handle_s {
     int dtype = CDH_F64, loss = CDH_LS, device = 0;
     int64_t n = 0, n_total = 0, row0 = 0, p = 0, ld = 0, nvec = 0;
@@ -136,6 +163,7 @@ struct cdh_handle_s {
     size_t h_xchg_doubles = 0;
     int64_t n_rccl_calls = 0, n_p2p_calls = 0, n_host_calls = 0;
     // profile
+    GradCache gc;
     bool prof = false;
     double prof_ms = 0.0, prof_bytes = 0.0;
     int64_t prof_launches = 0;
@@ -236,13 +264,15 @@ cdk::P2PCall next_p2p_call(cdh_handle h) {
 int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
     if (h->host_fn) {
         if (h->capturing) return fail(h, CDH_BAD_ARG, "the host-staged exchange cannot be recorded in a graph");
-        if (count > h->h_xchg_doubles) return fail(h, CDH_BAD_ARG, "host exchange: record longer than the staging buffer");
-        HIPCHK(h, hipMemcpyAsync(h->h_xchg, dbuf, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        const int32_t rc = h->host_fn(h->host_user, h->h_xchg, (int64_t)count);
-        if (rc != 0) return fail(h, CDH_RCCL_ERROR, "the host exchange callback reported a failure");
-        HIPCHK(h, hipMemcpyAsync(dbuf, h->h_xchg, sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));   // the staging buffer is reused by the next exchange
+        for (size_t o = 0; o < count; o += h->h_xchg_doubles) {   // long records go through the staging buffer in pieces
+            const size_t cnt = std::min(h->h_xchg_doubles, count - o);
+            HIPCHK(h, hipMemcpyAsync(h->h_xchg, dbuf + o, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            const int32_t rc = h->host_fn(h->host_user, h->h_xchg, (int64_t)cnt);
+            if (rc != 0) return fail(h, CDH_RCCL_ERROR, "the host exchange callback reported a failure");
+            HIPCHK(h, hipMemcpyAsync(dbuf + o, h->h_xchg, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));   // the staging buffer is reused by the next exchange
+        }
         h->n_host_calls += 1;
         return CDH_OK;
     }
@@ -311,6 +341,65 @@ int32_t resid_moments_dev(cdh_handle h) {  // -> d_red[0..2] = sum r, sum r^2, s
     return CDH_OK;
 }
 
+// ---- gradient cache: bookkeeping (the passes that use it are below run_chunk) ------------------------
+constexpr int kGcEngage = 3;        // mode 1: this many screened full passes run the plain way first
+constexpr int kGcBusy = 64;         // more inactive coordinates than this about to move: a plain pass is cheaper
+constexpr int kGcMaxFetch = 64;     // more uncached movers than this: re-reference instead of fetching their columns
+constexpr int kGcMaxSupport = 512;  // supports beyond this are not worth Gram columns
+constexpr size_t kGcMaxBytes = (size_t)1 << 30;
+
+inline bool gc_applicable(const cdh_handle_s* h) {
+    return h->gc.mode != 0 && h->dtype == CDH_F64 && !h->has_w && h->loss != CDH_WLS;
+}
+// g no longer describes r (y or the loss changed); with `columns` the Gram columns are gone too (X changed)
+void gc_invalidate(cdh_handle h, bool columns) {
+    GradCache& c = h->gc;
+    c.valid = false; c.beta_ok = false;
+    for (int64_t j : c.moved) { c.dbeta[(size_t)j] = 0.0; c.in_moved[(size_t)j] = 0; }
+    c.moved.clear();
+    if (columns) {
+        c.G.clear(); c.G.shrink_to_fit();
+        std::fill(c.slot.begin(), c.slot.end(), -1);
+        c.full_seen = 0;
+    }
+}
+// r was just set to y - X * (the handle's iterate) by a kernel: beta_ref follows; what changed against the
+// previous reference becomes pending moves (a warm start from another x is a move like any other)
+void gc_after_rebuild(cdh_handle h) {
+    GradCache& c = h->gc;
+    if (c.beta_ref.empty()) return;   // cache never sized (not applicable so far)
+    if (c.valid && !c.beta_ok) gc_invalidate(h, false);
+    std::vector<double> nb((size_t)h->p, 0.0);
+    for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) nb[(size_t)h->x.coord(s_)] = h->x.slot_value(s_);
+    if (c.valid) {
+        for (int64_t k = 0; k < h->p; ++k) {
+            const double d = nb[(size_t)k] - c.beta_ref[(size_t)k];
+            if (d != 0.0) {
+                c.dbeta[(size_t)k] += d;
+                if (!c.in_moved[(size_t)k]) { c.in_moved[(size_t)k] = 1; c.moved.push_back(k); }
+            }
+        }
+    }
+    c.beta_ref.swap(nb);
+    c.beta_ok = true;
+}
+// the visits of a chunk have been applied to r: remember what moved
+void gc_note_moves(cdh_handle h, const int64_t* idx0, int m) {
+    GradCache& c = h->gc;
+    if (!c.valid && !c.beta_ok) return;
+    for (int i = 0; i < m; ++i) {
+        const double hv = h->h_hs[i];
+        if (hv == 0.0) continue;
+        if (hv != hv) { gc_invalidate(h, false); return; }   // a NaN step: nothing is known about r any more
+        const int64_t k = idx0[i];
+        if (c.beta_ok) c.beta_ref[(size_t)k] += hv;
+        if (c.valid) {
+            c.dbeta[(size_t)k] += hv;
+            if (!c.in_moved[(size_t)k]) { c.in_moved[(size_t)k] = 1; c.moved.push_back(k); }
+        }
+    }
+}
+
 // ---- initialize!: upload support, r = y - X beta ------------------------------------
 int32_t rebuild_residual(cdh_handle h) {
     const int64_t nnz = h->x.nnz();
@@ -318,6 +407,7 @@ int32_t rebuild_residual(cdh_handle h) {
         HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->r, h->y, (size_t)h->ld * h->esz, hipMemcpyDeviceToDevice, h->stream));
         h->r_consistent = true;
+        gc_after_rebuild(h);
         return CDH_OK;
     }
     std::vector<double> dense((size_t)h->p, 0.0);
@@ -340,6 +430,7 @@ int32_t rebuild_residual(cdh_handle h) {
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors above go out of scope
     h->r_consistent = true;
+    gc_after_rebuild(h);
     return CDH_OK;
 }
 
@@ -502,7 +593,8 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     // all-reduces are recorded by RCCL itself as graph nodes.  Only the host-staged exchange cannot
     // be recorded.  A failed capture switches the handle back to node-by-node launches for good.
     bool launched = false;
-    if (h->use_graph && !h->graph_broken && !h->host_fn && !h->p2p_dead) {
+    // (a graph of one or two launches saves nothing and costs a capture: short chunks go node by node)
+    if (h->use_graph && !h->graph_broken && !h->host_fn && !h->p2p_dead && m >= (blocked ? 2 * h->blockB : 8)) {
         const uint64_t key = ((uint64_t)m << 20) | ((uint64_t)(blocked ? h->blockB : 0) << 8) |
                              (h->comm ? 32u : 0u) | (h->p2p_on ? 16u : 0u) |
                              (h->chunk_dup ? 4u : 0u) | (h->has_w ? 2u : 0u) | (h->nt ? 1u : 0u);
@@ -561,6 +653,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
         if (h->h_touched[i] && h->x.get(k) == 0.0) h->x.set(k, 1.0);  // pre-prox non-zero: slot appended
         h->x.set(k, h->h_newval[i]);
     }
+    gc_note_moves(h, idx0, m);
     if (h->prof) {
         float ms = 0.f;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -590,6 +683,239 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     return CDH_OK;
 }
 
+// ---- gradient cache: the certified full pass -------------------------------------------------------------
+int32_t gc_size(cdh_handle h) {   // first use on this handle
+    GradCache& c = h->gc;
+    if (!c.g.empty()) return CDH_OK;
+    const size_t p = (size_t)h->p;
+    c.g.assign(p, 0.0); c.a.assign(p, 0.0); c.dbeta.assign(p, 0.0);
+    c.in_moved.assign(p, 0); c.slot.assign(p, -1);
+    c.beta_ref.assign(p, 0.0);
+    c.beta_ok = h->r_consistent;          // r == y - X * (the handle's iterate) right now?
+    if (c.beta_ok)
+        for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) c.beta_ref[(size_t)h->x.coord(s_)] = h->x.slot_value(s_);
+    const int64_t launches = (h->p + kCrossA - 1) / kCrossA;
+    HIPCHK(h, hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec));
+    HIPCHK(h, hipMalloc((void**)&c.d_cols, sizeof(int64_t) * (p + kCrossA + kCrossB)));
+    std::vector<int64_t> ident(p + kCrossA + kCrossB, 0);
+    for (size_t k = 0; k < p; ++k) ident[k] = (int64_t)k;
+    HIPCHK(h, hipMemcpy(c.d_cols, ident.data(), sizeof(int64_t) * ident.size(), hipMemcpyHostToDevice));
+    c.h_cross.assign((size_t)launches * kCrossRec, 0.0);
+    return CDH_OK;
+}
+
+// g = X'r and a = diag(X'X) from one dots-only pass over all of X: the new reference point
+int32_t gc_validate(cdh_handle h) {
+    GradCache& c = h->gc;
+    CHK(col_dots(h, 0, h->p, h->r, false));
+    std::vector<double> cd((size_t)(2 * h->p));
+    HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * h->p, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int64_t k = 0; k < h->p; ++k) { c.g[(size_t)k] = cd[(size_t)(2 * k)]; c.a[(size_t)k] = cd[(size_t)(2 * k + 1)]; }
+    for (int64_t j : c.moved) { c.dbeta[(size_t)j] = 0.0; c.in_moved[(size_t)j] = 0; }
+    c.moved.clear();
+    c.valid = true;
+    c.n_validate += 1;
+    return CDH_OK;
+}
+
+// Gram columns G_j = X'X_j for the coordinates in `cols` (those not cached yet), 16 per pass over X
+int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
+    GradCache& c = h->gc;
+    std::vector<int64_t> todo;
+    for (int64_t j : cols) if (c.slot[(size_t)j] < 0 && std::find(todo.begin(), todo.end(), j) == todo.end()) todo.push_back(j);
+    if (todo.empty()) return CDH_OK;
+    if ((c.G.size() + todo.size()) * (size_t)h->p * sizeof(double) > kGcMaxBytes) {
+        gc_invalidate(h, true);
+        c.mode = 0;                       // this problem's supports do not fit: plain screens from now on
+        return CDH_OK;
+    }
+    const int64_t launches = (h->p + kCrossA - 1) / kCrossA;
+    const int G = NGgrid(h, 4);
+    if ((size_t)G * kCrossRec > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partial buffer too small for the cross-product grid");
+    for (size_t b0 = 0; b0 < todo.size(); b0 += kCrossB) {
+        const int nbc = (int)std::min<size_t>(kCrossB, todo.size() - b0);
+        int64_t* d_b = c.d_cols + h->p + kCrossA;
+        HIPCHK(h, hipMemcpyAsync(d_b, todo.data() + b0, sizeof(int64_t) * (size_t)nbc, hipMemcpyHostToDevice, h->stream));
+        for (int64_t L = 0; L < launches; ++L) {
+            const int na = (int)std::min<int64_t>(kCrossA, h->p - L * kCrossA);
+            CHK(dispatch(h, [&](auto* t) {
+                using T = std::remove_pointer_t<decltype(t)>;
+                hipLaunchKernelGGL(k_cross<T>, dim3(G), dim3(64 * kGramWaves), 0, h->stream, (const T*)h->X, h->ld, h->nvec,
+                                   c.d_cols + L * kCrossA, na, d_b, nbc, h->d_partials);
+                return CDH_OK;
+            }));
+            hipLaunchKernelGGL(k_gram_reduce, dim3(kCrossRec / kReduceVals), dim3(64 * kReduceWaves), 0, h->stream,
+                               h->d_partials, G, kCrossRec, c.d_cross + L * kCrossRec);
+        }
+        HIPCHK(h, hipGetLastError());
+        CHK(allreduce(h, c.d_cross, (size_t)launches * kCrossRec));
+        HIPCHK(h, hipMemcpyAsync(c.h_cross.data(), c.d_cross, sizeof(double) * (size_t)launches * kCrossRec,
+                                 hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // also: todo[b0 ..] has been consumed
+        for (int b = 0; b < nbc; ++b) {
+            c.G.emplace_back((size_t)h->p, 0.0);
+            std::vector<double>& col = c.G.back();
+            for (int64_t k = 0; k < h->p; ++k) {
+                const int64_t L = k / kCrossA, i = k % kCrossA;
+                col[(size_t)k] = c.h_cross[(size_t)(L * kCrossRec + (i >> 4) * 256 + (i & 15) * 16 + b)];
+            }
+            c.slot[(size_t)todo[b0 + (size_t)b]] = (int32_t)(c.G.size() - 1);
+        }
+        c.n_batches += 1; c.n_columns += nbc;
+    }
+    return CDH_OK;
+}
+
+// g <- g - sum_j dbeta_j G_j over the pending moves (all of which must have their columns)
+void gc_fold(cdh_handle h) {
+    GradCache& c = h->gc;
+    for (int64_t j : c.moved) {
+        const double d = c.dbeta[(size_t)j];
+        const std::vector<double>& col = c.G[(size_t)c.slot[(size_t)j]];
+        if (d != 0.0)
+            for (int64_t k = 0; k < h->p; ++k) c.g[(size_t)k] -= d * col[(size_t)k];
+        c.dbeta[(size_t)j] = 0.0; c.in_moved[(size_t)j] = 0;
+    }
+    c.moved.clear();
+}
+
+int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH);
+
+// A full pass over idx0[0..m) from the cache.  *handled = false: the caller runs the pass the plain way.
+int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, bool* handled) {
+    GradCache& c = h->gc;
+    *handled = false;
+    c.full_seen += 1;
+    if (!gc_applicable(h) || (c.mode == 1 && c.full_seen <= kGcEngage)) return CDH_OK;
+    if (h->x.nnz() > kGcMaxSupport) return CDH_OK;
+    if (c.cooldown > 0) { c.cooldown -= 1; if (c.valid) gc_invalidate(h, false); return CDH_OK; }
+    CHK(gc_size(h));
+    if (c.mode == 0) return CDH_OK;
+    const double lam = h->ctrl.lambda0, nt = (double)h->n_total;
+    const std::vector<double>& om = h->h_omega;
+    // 1. a current g: fold the pending moves, fetching the columns that are missing; too many missing (or no
+    //    reference yet): one dots-only pass over X gives a fresh g instead
+    std::vector<int64_t> want;
+    if (c.valid) {
+        for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) want.push_back(j);
+        if ((int)want.size() > kGcMaxFetch) { gc_invalidate(h, false); want.clear(); }
+    }
+    if (!c.valid) {
+        const bool ok = c.beta_ok;
+        std::vector<double> keep;
+        if (ok) keep = c.beta_ref;
+        CHK(gc_validate(h));
+        c.beta_ok = ok;
+        if (ok) c.beta_ref.swap(keep);
+    }
+    for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_)       // the support moves in every pass: its columns first
+        if (c.slot[(size_t)h->x.coord(s_)] < 0) want.push_back(h->x.coord(s_));
+    double rnorm = 0.0;
+    auto refresh_rnorm = [&]() -> int32_t {
+        if (h->loss != CDH_SQRT) return CDH_OK;
+        CHK(resid_moments_dev(h));
+        HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        rnorm = std::sqrt(h->h_red[1]);
+        return CDH_OK;
+    };
+    auto thr_of = [&](int64_t k) {
+        const double w = h->has_omega ? om[(size_t)k] : 1.0;
+        return (h->loss == CDH_SQRT ? lam * w * rnorm : lam * nt * w) * (1.0 - 1e-9);
+    };
+    // settled = the exact visit would leave beta_k at zero and r untouched (zero columns take the exact path)
+    auto settled = [&](int64_t k) {
+        return h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0 && std::fabs(c.g[(size_t)k]) <= thr_of(k);
+    };
+    if (!want.empty()) {
+        // fill the last batch of 16 with the inactive coordinates nearest their threshold: the likeliest to
+        // enter the support next (on a lambda path: at one of the next lambdas)
+        const size_t room = (kCrossB - want.size() % kCrossB) % kCrossB;
+        if (room > 0 && c.moved.empty()) {
+            CHK(refresh_rnorm());
+            std::vector<std::pair<double, int64_t>> near;
+            for (int64_t k = 0; k < h->p; ++k)
+                if (c.slot[(size_t)k] < 0 && h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0)
+                    near.emplace_back(std::fabs(c.g[(size_t)k]) / thr_of(k), k);
+            const size_t take = std::min(room, near.size());
+            std::partial_sort(near.begin(), near.begin() + (std::ptrdiff_t)take, near.end(), std::greater<std::pair<double, int64_t>>());
+            for (size_t i = 0; i < take; ++i) want.push_back(near[i].second);
+        }
+        CHK(gc_fetch(h, want));
+        if (c.mode == 0) return CDH_OK;
+    }
+    for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return fail(h, CDH_BAD_ARG, "gradient cache: a moved coordinate has no Gram column");
+    gc_fold(h);
+    CHK(refresh_rnorm());
+    // 2. inactive coordinates about to move: many of them means the pass is mostly real visits anyway
+    std::vector<int64_t> enter;
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t k = idx0[i];
+        if (h->x.get(k) == 0.0 && !settled(k) && c.slot[(size_t)k] < 0) enter.push_back(k);
+    }
+    std::sort(enter.begin(), enter.end());
+    enter.erase(std::unique(enter.begin(), enter.end()), enter.end());
+    if ((int)enter.size() > kGcBusy) {   // busy: back off (1, 2, 4 ... 16 plain passes) so that dense problems pay next to nothing
+        c.cooldown = c.backoff; c.backoff = std::min(16, 2 * c.backoff);
+        gc_invalidate(h, false);
+        return CDH_OK;
+    }
+    c.backoff = 1;
+    if (!enter.empty()) {
+        // their columns now, with the nearest other candidates filling the batch
+        const size_t room = (kCrossB - enter.size() % kCrossB) % kCrossB;
+        std::vector<std::pair<double, int64_t>> near;
+        for (int64_t k = 0; k < h->p && room > 0; ++k)
+            if (c.slot[(size_t)k] < 0 && h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0 && settled(k))
+                near.emplace_back(std::fabs(c.g[(size_t)k]) / thr_of(k), k);
+        const size_t take = std::min(room, near.size());
+        std::partial_sort(near.begin(), near.begin() + (std::ptrdiff_t)take, near.end(), std::greater<std::pair<double, int64_t>>());
+        for (size_t i = 0; i < take; ++i) enter.push_back(near[i].second);
+        CHK(gc_fetch(h, enter));
+        if (c.mode == 0) return CDH_OK;
+    }
+    *handled = true;
+    c.n_passes += 1;
+    // 3. the walk: runs of settled visits are skipped (with the bookkeeping the reference's SparseIterate
+    //    would have seen); everything else is visited by the ordinary kernels, a few visits per chunk
+    const int B = (h->mode == CDH_SWEEP_BLOCK) ? h->blockB : 1;
+    const int64_t maxlen = std::min<int64_t>(h->cap, std::max<int64_t>(4 * B, 64));
+    int64_t pos = 0;
+    while (pos < m) {
+        const int64_t k = idx0[pos];
+        if (settled(k)) {
+            if (h->loss != CDH_SQRT && c.g[(size_t)k] != 0.0) h->x.set(k, 1.0);   // x[k] += b/a stores a slot ...
+            h->x.set(k, 0.0);                                                          // ... cdprox! zeroes it
+            c.n_certified += 1;
+            ++pos;
+            continue;
+        }
+        // exact visits [pos, end): up to the last unsettled position that is no more than 4 past the previous one
+        int64_t end = pos + 1;
+        for (int64_t q = pos + 1; q < m && q - end < 4 && end - pos < maxlen; ++q)
+            if (!settled(idx0[q])) end = q + 1;
+        CHK(run_chunk(h, idx0 + pos, (int)(end - pos), maxH));
+        c.n_exact += end - pos;
+        pos = end;
+        if (!c.valid) { *handled = true; break; }     // a NaN step: finish below the plain way
+        if (!c.moved.empty()) {
+            std::vector<int64_t> miss;
+            for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) miss.push_back(j);
+            if (!miss.empty()) { CHK(gc_fetch(h, miss)); if (c.mode == 0) break; }
+            gc_fold(h);
+            CHK(refresh_rnorm());
+        }
+    }
+    if (pos < m) {   // the cache went away mid-pass: the rest of the list the plain way, chunk by chunk
+        for (int64_t off = pos; off < m; off += h->cap) {
+            const int mm = (int)std::min<int64_t>(h->cap, m - off);
+            CHK(run_chunk(h, idx0 + off, mm, maxH));
+        }
+    }
+    return CDH_OK;
+}
+
 // _cdPass! (coordinate_descent.jl:94-110)
 // Screening of a FULL pass (exact, no reference counterpart).  A visit of a coordinate with
 // beta_k == 0 leaves everything unchanged unless |X_k'r| exceeds its threshold (LS: lambda n w_k,
@@ -605,6 +931,11 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
 constexpr int kScreen = 64, kScreenMax = 1024;
 
 int32_t screened_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH) {
+    {   // from the gradient cache when it is engaged: no read of X for the settled visits at all
+        bool handled = false;
+        CHK(gc_full_pass(h, idx0, m, maxH, &handled));
+        if (handled) return CDH_OK;
+    }
     const int B = (h->mode == CDH_SWEEP_BLOCK) ? h->blockB : 1;
     const double lam = h->ctrl.lambda0, nt = (double)h->n_total;
     const std::vector<double>& om = h->h_omega;
@@ -726,6 +1057,8 @@ void free_all(cdh_handle h) {
     for (void* m : h->p2p_mapped) (void)hipIpcCloseMemHandle(m);
     if (h->p2p_inbox) (void)hipFree(h->p2p_inbox);
     if (h->d_p2p_base) (void)hipFree(h->d_p2p_base);
+    if (h->gc.d_cross) (void)hipFree(h->gc.d_cross);
+    if (h->gc.d_cols) (void)hipFree(h->gc.d_cols);
     if (h->h_xchg) (void)hipHostFree(h->h_xchg);
     if (h->p2p_timeout) (void)hipHostFree(h->p2p_timeout);
     for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);
@@ -869,6 +1202,7 @@ int32_t cdh_set_X_cols(cdh_handle h, int64_t j0, int64_t ncols, const void* host
     NEED_H(h);
     if (ncols > 0) NEED_P(h, host);
     h->r_consistent = false;
+    gc_invalidate(h, true);
     if (j0 < 0 || ncols < 0 || j0 + ncols > h->p || ld < h->n) return fail(h, CDH_DIM_MISMATCH, "column block outside X");
     if (ncols == 0) return CDH_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -896,6 +1230,7 @@ int32_t cdh_set_y(cdh_handle h, const void* host_y) {
     NEED_H(h);
     NEED_P(h, host_y);
     h->r_consistent = false;
+    gc_invalidate(h, false);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(h->y, host_y, (size_t)h->n * h->esz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->r, h->y, (size_t)h->n * h->esz, hipMemcpyDeviceToDevice, h->stream));
@@ -925,6 +1260,7 @@ int32_t cdh_set_obs_weights(cdh_handle h, const void* host_w) {
     NEED_H(h);
     NEED_P(h, host_w);
     h->r_consistent = false;
+    gc_invalidate(h, true);
     if (h->loss != CDH_WLS) return fail(h, CDH_BAD_ARG, "observation weights need the CDH_WLS loss");
     HIPCHK(h, hipSetDevice(h->device));
     CHK(ensure_weights_buffer(h));
@@ -944,12 +1280,14 @@ int32_t cdh_set_loss(cdh_handle h, int32_t loss) {
     h->ctrl.loss = loss;          // goes to the device with the next chunk's control block
     h->has_w = false;             // a weighted loss gets its weights from cdh_set_obs_weights
     h->r_consistent = false;
+    gc_invalidate(h, false);
     h->domain_error = false;
     return CDH_OK;
 }
 
 static int32_t cdh_generate_impl(cdh_handle h, uint64_t seed, int64_t s, double noise, double* out_beta_star) {
     if (s < 0 || s > h->p) return fail(h, CDH_BAD_ARG, "need 0 <= s <= p");
+    gc_invalidate(h, true);
     HIPCHK(h, hipSetDevice(h->device));
     // planted coefficients: beta*_j = z_j (1 + u_j) (benchmark/cd_bench.jl:14), stream 2
     std::vector<double> bstar((size_t)std::max<int64_t>(s, 1), 0.0);
@@ -1285,6 +1623,24 @@ int32_t cdh_set_screening(cdh_handle h, int32_t on) {
     NEED_H(h);
     if (on < 0 || on > 2) return fail(h, CDH_BAD_ARG, "screening: 0 = never, 1 = solves, 2 = cdh_pass as well");
     h->screening = on;
+    return CDH_OK;
+}
+
+int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode) {
+    NEED_H(h);
+    if (mode < 0 || mode > 2) return fail(h, CDH_BAD_ARG, "gradient cache: 0 = off, 1 = after a few full passes, 2 = from the first");
+    if (mode == 0) gc_invalidate(h, true);
+    h->gc.mode = mode;
+    h->gc.cooldown = 0; h->gc.backoff = 1;
+    return CDH_OK;
+}
+
+int32_t cdh_cache_stats(cdh_handle h, int64_t* out6) {
+    NEED_H(h);
+    NEED_P(h, out6);
+    const GradCache& c = h->gc;
+    out6[0] = c.n_passes; out6[1] = c.n_certified; out6[2] = c.n_exact;
+    out6[3] = c.n_validate; out6[4] = c.n_batches; out6[5] = c.n_columns;
     return CDH_OK;
 }
 

@@ -195,6 +195,16 @@ int32_t cdh_set_reuse_residual(cdh_handle h, int32_t on);
  * are the same as visiting one by one.  on: 0 = never, 1 = full passes of the solves (default; cdh_pass
  * visits every column it is given), 2 = cdh_pass as well. */
 int32_t cdh_set_screening(cdh_handle h, int32_t on);
+/* Gradient cache of the screened full passes (exact; fp64 storage, no observation weights).  With the Gram
+ * columns X'X_j of the coordinates that move, X_k'r is known for every k without reading X, so a full pass
+ * over a sparse iterate costs its real visits only -- what a lambda path (lasso.jl:250-252), the sigma loop
+ * of scaledLasso! (:132-141) or a cold start's 51 solves (coordinate_descent.jl:32-36) repeat hundreds of
+ * times on one X.  mode: 0 off, 1 (default) engages after three screened full passes on the same data,
+ * 2 from the first.  Same iterates, support order and pass counts as visiting every coordinate.
+ * cdh_cache_stats: out6 = {passes served, visits settled from the cache, visits made, dots-only
+ * re-reference passes over X, 16-column Gram batches (1.25 passes over X each), Gram columns held}. */
+int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode);
+int32_t cdh_cache_stats(cdh_handle h, int64_t *out6);
 /* Replay each pass from a captured hipGraph instead of individual launches (the north_star's
  * "full sweep captured under hipGraph").  Works on row shards too: the direct exchange takes its epoch
  * from device memory, RCCL all-reduces are captured with the kernels around them; only the host-staged

@@ -73,6 +73,28 @@ def main():
         cp.barrier()
         f.close()
 
+    # a warm-started lambda path on shards with the gradient cache from the first full pass: the dots-only
+    # reference pass and the Gram-column batches (80 K cross products per all-reduce) go through the seam too
+    n2, p2 = 6000, 520
+    X2 = np.asfortranarray(rng.standard_normal((n2, p2)))
+    y2 = X2[:, :9] @ (2 * rng.standard_normal(9)) + rng.standard_normal(n2)
+    r0, nl2 = sharded.shard_rows(n2, cp.rank, cp.world)
+    f = cd.CDLeastSquaresLoss(y2[r0:r0 + nl2], X2[r0:r0 + nl2], device=0, n_total=n2, row_offset=r0)
+    sharded.connect_host(f, cp)
+    f.set_gradient_cache(2)
+    fo = O.CDLeastSquaresLoss(y2, X2)
+    x, xo = cd.SparseIterate(p2), O.SparseIterate(p2)
+    for lam in (0.4, 0.2, 0.1, 0.05):
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        assert float(np.max(np.abs(x.dense() - xo.dense()))) < 1e-10, lam
+        assert f.last_stats["passes"] == st["passes"] and sorted(x.nzval2ind.tolist()) == sorted(xo.nzval2ind.tolist())
+        assert same_on_all_ranks(x.dense())
+    cs = f.cache_stats()
+    assert cs["passes"] >= 4 and cs["settled_visits"] > cs["exact_visits"] > 0 and cs["gram_columns"] >= xo.nnz, cs
+    cp.barrier()
+    f.close()
+
     # scaledLasso! on shards: the :Screening init (X'y scores, the s x s normal equations through cdh_gram,
     # std of the OLS residuals) and the sigma loop all go through the seam
     f = shard(cd.CDLeastSquaresLoss)

@@ -847,3 +847,94 @@ def test_reference_benchmark_shape():
     assert f.last_stats["passes"] == st["passes"] == 40 and not st["converged"]
     np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-8)
     np.testing.assert_allclose(cd.objective(f), O.objective(fo, O.ProxL1(0.001), xo), rtol=1e-10)
+
+
+# ---- gradient cache: full passes served from cached X'r + Gram columns of the coordinates that moved ---------
+@pytest.mark.parametrize("loss", ["ls", "wl1", "sqrt"])
+@pytest.mark.parametrize("rand", [False, True], ids=["ordered", "random"])
+def test_gradient_cache_path_matches_oracle_and_plain_passes(loss, rand):
+    """A 14-lambda warm-started path on one handle, three ways: gradient cache from the first full pass
+    (mode 2), the default (mode 1: engages after three screened full passes), and off (mode 0: dots-only
+    screens).  Same beta as the oracle at every lambda (1e-10), same support ORDER and the same number of
+    passes in all three: the cache skips a visit only when the exact path would have left the coordinate
+    at zero."""
+    rng, X, Y = _problem(51, 3000, 640, 14, noise=1.0)
+    X *= rng.uniform(0.5, 2.0, size=640)
+    om = (rng.random(640) + 0.5) if loss == "wl1" else None
+    top = 3.6 if loss == "sqrt" else 0.3
+    lams = np.exp(np.linspace(np.log(top), np.log((0.6 if loss == "sqrt" else 0.12) * top), 14))
+    # optTol 1e-10: a pass count is only comparable when the last maxH does not sit within rounding of the
+    # tolerance (the sqrt-lasso closed form carries ~1e-13 of cancellation noise in h)
+    o = dict(maxIter=3000, optTol=1e-10, randomize=rand, seed=13)
+    cls, ocls = (cd.CDSqrtLassoLoss, O.CDSqrtLassoLoss) if loss == "sqrt" else (cd.CDLeastSquaresLoss, O.CDLeastSquaresLoss)
+    xo, fo, want = O.SparseIterate(640), ocls(Y, X), []
+    for lam in lams:
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam, om), O.CDOptions(**o))
+        want.append((xo.dense().copy(), xo.nzval2ind.tolist(), st["passes"]))
+    assert 10 < xo.nnz < 160
+    stats = {}
+    for mode in (2, 1, 0):
+        f = cls(Y, X)
+        f.set_sweep_mode("block", 16)
+        f.set_gradient_cache(mode)
+        x = cd.SparseIterate(640)
+        for lam, (beta, sup, passes) in zip(lams, want):
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(**o))
+            np.testing.assert_allclose(x.dense(), beta, rtol=0, atol=BETA_TOL)
+            assert x.nzval2ind.tolist() == sup and f.last_stats["passes"] == passes, (mode, lam)
+        np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-9)
+        stats[mode] = f.cache_stats()
+        f.close()
+    assert stats[0]["passes"] == 0 and stats[0]["gram_columns"] == 0
+    for mode in (2, 1):
+        s = stats[mode]
+        assert s["passes"] >= 10 and s["settled_visits"] > 5 * s["exact_visits"] > 0, s
+        assert s["gram_columns"] >= xo.nnz and s["reference_passes"] <= 3, s
+
+
+def test_gradient_cache_follows_new_iterates_new_y_and_cold_starts():
+    """What invalidates or shifts the cached gradient: a warm start from a DIFFERENT x (the difference is
+    folded in as moves), a cold start (x zeroed, 51 continuation solves -- all served from the cache), a
+    new y on the same X (gradient re-referenced, Gram columns kept), a new X (everything dropped)."""
+    rng, X, Y = _problem(52, 2500, 520, 10)
+    Y2 = X[:, 100:108] @ rng.standard_normal(8) + rng.standard_normal(2500)
+    o = dict(maxIter=3000, optTol=1e-12, randomize=False)
+    f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+    f.set_gradient_cache(2)
+    x, xo = cd.SparseIterate(520), O.SparseIterate(520)
+
+    def both(lam, **kw):
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**dict(o, **kw)))
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**dict(o, **kw)))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"]
+
+    both(0.2)
+    both(0.1)
+    x0 = np.where(rng.random(520) < 0.02, rng.standard_normal(520), 0.0)     # a different starting point
+    x, xo = cd.SparseIterate(520, x0), O.SparseIterate(520, x0)
+    both(0.1)
+    both(0.07)
+    before = f.cache_stats()
+    both(0.05, warmStart=False)                                              # cold start: 51 solves
+    after = f.cache_stats()
+    assert after["passes"] - before["passes"] >= 51 and after["reference_passes"] - before["reference_passes"] <= 1
+    cols = after["gram_columns"]
+    # a new y on the same matrix (what the Julia binding does between two lasso() calls on one HipMatrix)
+    y2 = np.ascontiguousarray(Y2)
+    cd._lib.check(f._L.cdh_set_y(f._h, y2.ctypes.data), f._h)
+    fo = O.CDLeastSquaresLoss(Y2, X)
+    x, xo = cd.SparseIterate(520), O.SparseIterate(520)
+    both(0.2)
+    both(0.08)
+    assert f.cache_stats()["gram_columns"] >= cols                           # the columns survived the new y
+    # new columns in X: the cache must forget everything
+    Xn = np.asfortranarray(X.copy())
+    Xn[:, :40] = rng.standard_normal((2500, 40))
+    blk = np.asfortranarray(Xn[:, :40])
+    cd._lib.check(f._L.cdh_set_X_cols(f._h, 0, 40, blk.ctypes.data, 2500), f._h)
+    fo = O.CDLeastSquaresLoss(Y2, Xn)
+    x, xo = cd.SparseIterate(520), O.SparseIterate(520)
+    both(0.2)
+    both(0.08)
+    f.close()

@@ -21,6 +21,8 @@ def cfg3(n=2_000_000, p=5000, nlam=100):
     f, _ = cd.CDLeastSquaresLoss.generate(n, p, seed=123, s=100, noise=6.0)
     f.set_sweep_mode(os.environ.get("CFG_MODE", "block"), int(os.environ.get("CFG_BLOCK", "16")))
     f.set_use_graph(bool(int(os.environ.get("CFG_GRAPH", "0"))))
+    f.set_gradient_cache(int(os.environ.get("CFG_CACHE", "1")))
+    f.set_screening(int(os.environ.get("CFG_SCREEN", "1")))
     x = cd.SparseIterate(p)
     cd.initialize_(f, x)
     om = cd.stdX(f)
@@ -38,7 +40,7 @@ def cfg3(n=2_000_000, p=5000, nlam=100):
     sync(f)
     dt = time.perf_counter() - t0
     return dict(config="cfg3 lasso path", n=n, p=p, lambdas=nlam, seconds=dt, passes=passes, visits=visits,
-                visits_per_s=visits / dt, nnz_last=nnz[-1], nnz_max=max(nnz))
+                visits_per_s=visits / dt, nnz_last=nnz[-1], nnz_max=max(nnz), cache=f.cache_stats())
 
 
 def cfg4_shard(n=5_000_000, p=1000):
