@@ -679,6 +679,8 @@ def LassoPath(X, Y, lambdapath, options=None, max_hat_s=np.inf, standardizeX=Tru
     # x and f are shared by all lambdas; after the first solve the carried residual already
     # equals y - X x, so later warm starts skip the redundant initialize! (rounding-level effect)
     check(f._L.cdh_set_reuse_residual(f._h, 1 if reuse_residual else 0), f._h)
+    # a path is many solves on one X: the gradient cache need not wait for evidence of that (mode 2)
+    check(f._L.cdh_set_gradient_cache(f._h, 2), f._h)
     try:
         for i, lam in enumerate(lambdapath):
             coordinateDescent_(x, f, ProxL1(lam, sx), options)
@@ -688,4 +690,5 @@ def LassoPath(X, Y, lambdapath, options=None, max_hat_s=np.inf, standardizeX=Tru
                 break
     finally:
         check(f._L.cdh_set_reuse_residual(f._h, 0), f._h)
+        check(f._L.cdh_set_gradient_cache(f._h, 1), f._h)
     return LassoPathResult(lambdapath, betapath)

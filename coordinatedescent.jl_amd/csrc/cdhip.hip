@@ -77,7 +77,7 @@ constexpr int kNcclSum = 0;
 //   X'r = g_ref - sum_j dbeta_j G_j .
 // Only the support ever moves, so a handle that keeps solving on the same X (a lambda path, the sigma loop
 // of scaledLasso!, the 51 continuation solves of a cold start) pays one pass over X for g_ref, 1.25 passes
-// per 16 Gram columns as coordinates enter the support, and after that a full pass costs its exact visits
+// per 32 Gram columns as coordinates enter the support, and after that a full pass costs its exact visits
 // only.  Same iterates as visiting one by one: a coordinate is skipped only when the exact path would have
 // left it at zero (1e-9 relative margin, as for the dots-only screens), everything else is visited by the
 // same kernels.  fp64 storage, no observation weights.
@@ -92,8 +92,8 @@ struct GradCache {
     std::vector<uint8_t> in_moved;
     std::vector<int32_t> slot;      // coordinate -> Gram column, -1 = not cached
     std::vector<std::vector<double>> G;
-    double* d_cross = nullptr;      // device: ceil(p / 64) records of 1024 cross products
-    int64_t* d_cols = nullptr;      // device: 0 .. p-1 (A operand lists) followed by the 16 B columns of a batch
+    double* d_cross = nullptr;      // device: ceil(p / 64) records of 64 x 32 cross products
+    int64_t* d_cols = nullptr;      // device: 0 .. p-1 (A operand lists) followed by the B columns of a batch
     std::vector<double> h_cross;
     int64_t n_validate = 0, n_batches = 0, n_columns = 0, n_certified = 0, n_exact = 0, n_passes = 0;
 };
@@ -719,7 +719,7 @@ int32_t gc_validate(cdh_handle h) {
     return CDH_OK;
 }
 
-// Gram columns G_j = X'X_j for the coordinates in `cols` (those not cached yet), 16 per pass over X
+// Gram columns G_j = X'X_j for the coordinates in `cols` (those not cached yet), up to 32 per pass over X
 int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
     GradCache& c = h->gc;
     std::vector<int64_t> todo;
@@ -758,7 +758,7 @@ int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
             std::vector<double>& col = c.G.back();
             for (int64_t k = 0; k < h->p; ++k) {
                 const int64_t L = k / kCrossA, i = k % kCrossA;
-                col[(size_t)k] = c.h_cross[(size_t)(L * kCrossRec + (i >> 4) * 256 + (i & 15) * 16 + b)];
+                col[(size_t)k] = c.h_cross[(size_t)(L * kCrossRec + ((i >> 4) * kCrossTB + (b >> 4)) * 256 + (i & 15) * 16 + (b & 15))];
             }
             c.slot[(size_t)todo[b0 + (size_t)b]] = (int32_t)(c.G.size() - 1);
         }
@@ -787,7 +787,10 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     GradCache& c = h->gc;
     *handled = false;
     c.full_seen += 1;
-    if (!gc_applicable(h) || (c.mode == 1 && c.full_seen <= kGcEngage)) return CDH_OK;
+    // mode 1 buys the Gram columns of the support (1.5 passes over X per 32 of them) only after the handle has
+    // paid that much in plain full passes on the same data: at most twice the cost of having known in advance
+    const int64_t rent = std::max<int64_t>(kGcEngage, 1 + (3 * h->x.nnz()) / 64);
+    if (!gc_applicable(h) || (c.mode == 1 && !c.valid && c.full_seen <= rent)) return CDH_OK;
     if (h->x.nnz() > kGcMaxSupport) return CDH_OK;
     if (c.cooldown > 0) { c.cooldown -= 1; if (c.valid) gc_invalidate(h, false); return CDH_OK; }
     CHK(gc_size(h));
@@ -829,7 +832,7 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
         return h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0 && std::fabs(c.g[(size_t)k]) <= thr_of(k);
     };
     if (!want.empty()) {
-        // fill the last batch of 16 with the inactive coordinates nearest their threshold: the likeliest to
+        // fill the last batch of 32 with the inactive coordinates nearest their threshold: the likeliest to
         // enter the support next (on a lambda path: at one of the next lambdas)
         const size_t room = (kCrossB - want.size() % kCrossB) % kCrossB;
         if (room > 0 && c.moved.empty()) {
@@ -1467,6 +1470,8 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
         rc = [&]() -> int32_t {                         // whatever happens below, lambda0 is put back
             h->x.clear();                               // fill!(x, 0)           (:25)
             CHK(rebuild_residual(h));                   // initialize!(f, x)     (:26)
+            // 51 solves on the same X follow: the gradient cache (mode 1) need not wait for evidence
+            h->gc.full_seen = std::max<int64_t>(h->gc.full_seen, 1000);
             double lmax = 0.0;
             CHK(lambda_max(h, &lmax));                  // _findLambdaMax        (:29)
             st.lambda_max = lmax;

@@ -537,15 +537,16 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
     }
 }
 
-// Cross products of up to 64 columns (A) with up to 16 columns (B) in one pass over both sets:
-//   partials[block][t * 256 + i * 16 + j] = X_{A[16 t + i]}' X_{B[j]}   (this block's rows)
+// Cross products of up to 64 columns (A) with up to 32 columns (B) in one pass over both sets:
+//   partials[block][(2 ta + tb) * 256 + i * 16 + j] = X_{A[16 ta + i]}' X_{B[16 tb + j]}   (this block's rows)
 // The Gram COLUMNS the gradient cache keeps for the coordinates that move (cdhip.hip, GradCache): with
 // G_j = X'X_j for every moved j, X_k'r is known for every k without reading X again.  Same use of the
 // matrix pipe as k_gramstep -- a 16 x 16 fp64 accumulator tile in 8 registers, rows of X as the K
-// dimension, lane (c, g) loading 16 bytes of column c at vector 4u + g -- with separate A and B operands.
-// HBM-bound: (64 + 16) columns read for 64 x 16 products, 1.25 passes over X per 16 Gram columns.
-// fp32 storage is widened to fp64 on the way in (an occasional pass, not the sweep).
-constexpr int kCrossA = 64, kCrossB = 16, kCrossRec = 4 * 256;
+// dimension, lane (c, g) loading 16 bytes of column c at vector 4u + g -- with separate A and B operands
+// (4 x 2 tiles).  HBM-bound: (64 + nb) columns read for 64 x nb products -- B columns that are not
+// asked for are not loaded -- i.e. 1.5 passes over X per 32 Gram columns.  fp32 storage is widened to
+// fp64 on the way in (an occasional pass, not the sweep).
+constexpr int kCrossA = 64, kCrossB = 32, kCrossTA = 4, kCrossTB = 2, kCrossRec = kCrossTA * kCrossTB * 256;
 template <typename T>
 __global__ __launch_bounds__(64 * kGramWaves, 2) void k_cross(const T* __restrict__ X, int64_t ld, int64_t nvec,
                                                               const int64_t* __restrict__ acols, int na,
@@ -555,47 +556,60 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_cross(const T* __restric
     constexpr int NV = VecOf<T>::N;
     __shared__ double s_red[kGramWaves][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const V* av[4];
-    bool aact[4];
+    const V* av[kCrossTA];
+    const V* bv[kCrossTB];
+    bool aact[kCrossTA], bact[kCrossTB];
 #pragma unroll
-    for (int grp = 0; grp < 4; ++grp) {
+    for (int grp = 0; grp < kCrossTA; ++grp) {
         const int i = 16 * grp + c;
         aact[grp] = i < na;
         av[grp] = reinterpret_cast<const V*>(X + acols[aact[grp] ? i : 0] * ld);
     }
-    const bool bact = c < nbc;
-    const V* bv = reinterpret_cast<const V*>(X + bcols[bact ? c : 0] * ld);
-    dvec4 tile[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) tile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
+    for (int grp = 0; grp < kCrossTB; ++grp) {
+        const int j = 16 * grp + c;
+        bact[grp] = j < nbc;
+        bv[grp] = reinterpret_cast<const V*>(X + bcols[bact[grp] ? j : 0] * ld);
+    }
+    dvec4 tile[kCrossTA * kCrossTB];
+#pragma unroll
+    for (int t = 0; t < kCrossTA * kCrossTB; ++t) tile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
     const int64_t nchunks = (nvec + 63) / 64;
     for (int64_t ch = (int64_t)wave * gridDim.x + blockIdx.x; ch < nchunks; ch += (int64_t)gridDim.x * kGramWaves) {
         const int64_t v0 = ch * 64;
 #pragma unroll 1
         for (int u0 = 0; u0 < 16; u0 += 4) {
-            V xa[4][4], xb[4];
+            V xa[4][kCrossTA], xb[4][kCrossTB];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t v = v0 + 4 * (u0 + u) + g;
                 const bool in = v < nvec;
-                xb[u] = (bact && in) ? ld_stream<true>(bv + v) : vzero((V*)nullptr);
 #pragma unroll
-                for (int grp = 0; grp < 4; ++grp)
+                for (int grp = 0; grp < kCrossTB; ++grp)
+                    xb[u][grp] = (bact[grp] && in) ? ld_stream<true>(bv[grp] + v) : vzero((V*)nullptr);
+#pragma unroll
+                for (int grp = 0; grp < kCrossTA; ++grp)
                     xa[u][grp] = (aact[grp] && in) ? ld_stream<true>(av[grp] + v) : vzero((V*)nullptr);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int e = 0; e < NV; ++e) {
-                    const double b = (double)xb[u][e];
+                    double b[kCrossTB];
 #pragma unroll
-                    for (int grp = 0; grp < 4; ++grp)
-                        tile[grp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xa[u][grp][e], b, tile[grp], 0, 0, 0);
+                    for (int gb = 0; gb < kCrossTB; ++gb) b[gb] = (double)xb[u][gb][e];
+#pragma unroll
+                    for (int ga = 0; ga < kCrossTA; ++ga) {
+                        const double a = (double)xa[u][ga][e];
+#pragma unroll
+                        for (int gb = 0; gb < kCrossTB; ++gb)
+                            tile[ga * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[gb], tile[ga * kCrossTB + gb], 0, 0, 0);
+                    }
                 }
         }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < kCrossTA * kCrossTB; ++t) {
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) s_red[wave][(g + 4 * q4) * 16 + c] = tile[t][q4];   // D[i = g + 4 q4][j = c]
         __syncthreads();

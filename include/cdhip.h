@@ -199,10 +199,13 @@ int32_t cdh_set_screening(cdh_handle h, int32_t on);
  * columns X'X_j of the coordinates that move, X_k'r is known for every k without reading X, so a full pass
  * over a sparse iterate costs its real visits only -- what a lambda path (lasso.jl:250-252), the sigma loop
  * of scaledLasso! (:132-141) or a cold start's 51 solves (coordinate_descent.jl:32-36) repeat hundreds of
- * times on one X.  mode: 0 off, 1 (default) engages after three screened full passes on the same data,
- * 2 from the first.  Same iterates, support order and pass counts as visiting every coordinate.
+ * times on one X.  mode: 0 off; 1 (default) engages once the handle has run as many screened full passes on
+ * the same data as the Gram columns of its support cost to fetch (at least three; a cold start engages at
+ * once); 2 from the first full pass (what a path driver that knows it has 100 lambdas to go asks for).
+ * Same iterates, support order and pass counts as visiting every coordinate.
  * cdh_cache_stats: out6 = {passes served, visits settled from the cache, visits made, dots-only
- * re-reference passes over X, 16-column Gram batches (1.25 passes over X each), Gram columns held}. */
+ * re-reference passes over X, Gram batches (up to 32 columns, at most 1.5 passes over X each), Gram
+ * columns held}. */
 int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode);
 int32_t cdh_cache_stats(cdh_handle h, int64_t *out6);
 /* Replay each pass from a captured hipGraph instead of individual launches (the north_star's

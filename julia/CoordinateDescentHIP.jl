@@ -262,12 +262,16 @@ end
 # _findInitSigma!(X, y, s, storage) = std(_findInitResiduals!(X, y, s, storage)) (utils.jl:60-64) is
 # generic and lands in the method above.
 
-# Optional knobs (no reference counterpart): blocked sweep width, screened full passes, hipGraph
-# replay, reuse of the carried residual by warm starts (what LassoPath wants: src/lasso.jl:250-252).
+# Optional knobs (no reference counterpart): blocked sweep width, screened full passes, the gradient
+# cache of repeated solves, hipGraph replay, reuse of the carried residual by warm starts (what LassoPath
+# wants: src/lasso.jl:250-252).
 set_sweep_mode!(X::HipMatrix, blocked::Bool, block::Integer=32) =
   check(X.handle, ccall((:cdh_set_sweep_mode, libcdhip), Int32, (Ptr{Cvoid}, Int32, Int32), X.handle, blocked ? 1 : 0, block))
 set_screening!(X::HipMatrix, level::Integer) =
   check(X.handle, ccall((:cdh_set_screening, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, level))
+"0 off, 1 (default) engages once it has paid for itself, 2 from the first full pass: ask for 2 before LassoPath"
+set_gradient_cache!(X::HipMatrix, mode::Integer) =
+  check(X.handle, ccall((:cdh_set_gradient_cache, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, mode))
 set_use_graph!(X::HipMatrix, on::Bool) =
   check(X.handle, ccall((:cdh_set_use_graph, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, on ? 1 : 0))
 set_reuse_residual!(X::HipMatrix, on::Bool) =

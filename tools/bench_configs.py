@@ -21,7 +21,7 @@ def cfg3(n=2_000_000, p=5000, nlam=100):
     f, _ = cd.CDLeastSquaresLoss.generate(n, p, seed=123, s=100, noise=6.0)
     f.set_sweep_mode(os.environ.get("CFG_MODE", "block"), int(os.environ.get("CFG_BLOCK", "16")))
     f.set_use_graph(bool(int(os.environ.get("CFG_GRAPH", "0"))))
-    f.set_gradient_cache(int(os.environ.get("CFG_CACHE", "1")))
+    f.set_gradient_cache(int(os.environ.get("CFG_CACHE", "2")))     # a path: what cd.LassoPath asks for
     f.set_screening(int(os.environ.get("CFG_SCREEN", "1")))
     x = cd.SparseIterate(p)
     cd.initialize_(f, x)
