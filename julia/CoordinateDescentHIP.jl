@@ -113,6 +113,12 @@ function upload_y!(X::HipMatrix{T}, y::AbstractVector{T}) where {T}
   GC.@preserve yy check(X.handle, ccall((:cdh_set_y, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), X.handle, yy))
 end
 
+function upload_w!(X::HipMatrix{T}, w::AbstractVector{T}) where {T}
+  length(w) == X.n || throw(DimensionMismatch())
+  ww = w isa Vector{T} ? w : Vector{T}(w)
+  GC.@preserve ww check(X.handle, ccall((:cdh_set_obs_weights, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), X.handle, ww))
+end
+
 "Make the handle serve THIS loss object: its kind (the Julia type decides, never a flag given at upload
 time), its y (and w).  A loss object is bound when first used and re-bound whenever another loss used
 the same HipMatrix in between -- `lasso(Xh, y2, λ)` after `lasso(Xh, y1, λ)` solves against y2, and a
@@ -127,11 +133,7 @@ function rebind!(f::HipLoss{T}) where {T}
   X = f.X
   set_loss!(X, loss_kind(f))
   upload_y!(X, f.y)                                   # also r = copy(y), as the loss constructors do
-  if f isa HipWLS
-    w = f.w isa Vector{T} ? f.w : Vector{T}(f.w)
-    length(w) == X.n || throw(DimensionMismatch())
-    GC.@preserve w check(X.handle, ccall((:cdh_set_obs_weights, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), X.handle, w))
-  end
+  f isa HipWLS && upload_w!(X, f.w)
   X.owner = objectid(f.r)
   f
 end
