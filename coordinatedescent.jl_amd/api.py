@@ -288,7 +288,7 @@ class _HipLoss(CoordinateDifferentiableFunction):
         check(self._L.cdh_set_screening(self._h, int(on)), self._h)
 
     def set_gradient_cache(self, mode=1):
-        """0 off, 1 engage after three screened full passes on the same data (default), 2 from the first."""
+        """0 off, 1 rent-or-buy (default), 2 from the first full pass, 3 = 2 without the tall-problem guard."""
         check(self._L.cdh_set_gradient_cache(self._h, int(mode)), self._h)
 
     def cache_stats(self):

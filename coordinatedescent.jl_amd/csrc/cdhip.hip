@@ -82,7 +82,8 @@ constexpr int kNcclSum = 0;
 // left it at zero (1e-9 relative margin, as for the dots-only screens), everything else is visited by the
 // same kernels.  fp64 storage, no observation weights.
 struct GradCache {
-    int mode = 1;                   // 0 off, 1 engages after kGcEngage screened full passes, 2 from the first one
+    int mode = 1;                   // 0 off, 1 rent-or-buy, 2 from the first full pass (both only where the host-side
+                                    // fold is cheaper than reading X), 3 from the first full pass, unconditionally
     bool valid = false;             // g (with the pending dbeta) describes X'r of the device's current r
     bool beta_ok = false;           // r == y - X beta_ref up to rounding
     int64_t full_seen = 0;          // screened full passes since the data last changed
@@ -347,6 +348,7 @@ constexpr int kGcBusy = 64;         // more inactive coordinates than this about
 constexpr int kGcMaxFetch = 64;     // more uncached movers than this: re-reference instead of fetching their columns
 constexpr int kGcMaxSupport = 512;  // supports beyond this are not worth Gram columns
 constexpr size_t kGcMaxBytes = (size_t)1 << 30;
+constexpr int64_t kGcRowsPerNnz = 400;   // rows the problem must have per non-zero for the host-side fold to pay
 
 inline bool gc_applicable(const cdh_handle_s* h) {
     return h->gc.mode != 0 && h->dtype == CDH_F64 && !h->has_w && h->loss != CDH_WLS;
@@ -791,6 +793,13 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     // paid that much in plain full passes on the same data: at most twice the cost of having known in advance
     const int64_t rent = std::max<int64_t>(kGcEngage, 1 + (3 * h->x.nnz()) / 64);
     if (!gc_applicable(h) || (c.mode == 1 && !c.valid && c.full_seen <= rent)) return CDH_OK;
+    // Folding a moved coordinate into g is p host flops (~0.5 ns each); reading X once is n p sz bytes at
+    // ~6 TB/s.  The cache only pays while nnz * p * 0.5 ns stays well under that, i.e. for n >> 400 nnz:
+    // short-and-wide problems (the reference's own n = 3000, p = 5000 shape) keep the dots-only screens.
+    if (c.mode != 3 && h->x.nnz() * kGcRowsPerNnz > h->n_total) {
+        if (c.valid) gc_invalidate(h, false);
+        return CDH_OK;
+    }
     if (h->x.nnz() > kGcMaxSupport) return CDH_OK;
     if (c.cooldown > 0) { c.cooldown -= 1; if (c.valid) gc_invalidate(h, false); return CDH_OK; }
     CHK(gc_size(h));
@@ -1633,7 +1642,7 @@ int32_t cdh_set_screening(cdh_handle h, int32_t on) {
 
 int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode) {
     NEED_H(h);
-    if (mode < 0 || mode > 2) return fail(h, CDH_BAD_ARG, "gradient cache: 0 = off, 1 = after a few full passes, 2 = from the first");
+    if (mode < 0 || mode > 3) return fail(h, CDH_BAD_ARG, "gradient cache: 0 = off, 1 = rent-or-buy, 2 = from the first full pass, 3 = 2 without the size guard");
     if (mode == 0) gc_invalidate(h, true);
     h->gc.mode = mode;
     h->gc.cooldown = 0; h->gc.backoff = 1;

@@ -202,6 +202,8 @@ int32_t cdh_set_screening(cdh_handle h, int32_t on);
  * times on one X.  mode: 0 off; 1 (default) engages once the handle has run as many screened full passes on
  * the same data as the Gram columns of its support cost to fetch (at least three; a cold start engages at
  * once); 2 from the first full pass (what a path driver that knows it has 100 lambdas to go asks for).
+ * Modes 1 and 2 engage only while n_total >= 400 * nnz(x): folding a move into the cached gradient is p host
+ * flops, which beats re-reading X only on tall problems; mode 3 is mode 2 without that guard (tests).
  * Same iterates, support order and pass counts as visiting every coordinate.
  * cdh_cache_stats: out6 = {passes served, visits settled from the cache, visits made, dots-only
  * re-reference passes over X, Gram batches (up to 32 columns, at most 1.5 passes over X each), Gram

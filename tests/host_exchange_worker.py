@@ -81,7 +81,7 @@ def main():
     r0, nl2 = sharded.shard_rows(n2, cp.rank, cp.world)
     f = cd.CDLeastSquaresLoss(y2[r0:r0 + nl2], X2[r0:r0 + nl2], device=0, n_total=n2, row_offset=r0)
     sharded.connect_host(f, cp)
-    f.set_gradient_cache(2)
+    f.set_gradient_cache(3)
     fo = O.CDLeastSquaresLoss(y2, X2)
     x, xo = cd.SparseIterate(p2), O.SparseIterate(p2)
     for lam in (0.4, 0.2, 0.1, 0.05):

@@ -854,8 +854,8 @@ def test_reference_benchmark_shape():
 @pytest.mark.parametrize("rand", [False, True], ids=["ordered", "random"])
 def test_gradient_cache_path_matches_oracle_and_plain_passes(loss, rand):
     """A 14-lambda warm-started path on one handle, three ways: gradient cache from the first full pass
-    (mode 2), the default (mode 1: engages after three screened full passes), and off (mode 0: dots-only
-    screens).  Same beta as the oracle at every lambda (1e-10), same support ORDER and the same number of
+    (mode 3: unconditional), the default (mode 1: rent-or-buy, and only on tall problems), and off (mode 0:
+    dots-only screens).  Same beta as the oracle at every lambda (1e-10), same support ORDER and the same number of
     passes in all three: the cache skips a visit only when the exact path would have left the coordinate
     at zero."""
     rng, X, Y = _problem(51, 3000, 640, 14, noise=1.0)
@@ -873,7 +873,7 @@ def test_gradient_cache_path_matches_oracle_and_plain_passes(loss, rand):
         want.append((xo.dense().copy(), xo.nzval2ind.tolist(), st["passes"]))
     assert 10 < xo.nnz < 160
     stats = {}
-    for mode in (2, 1, 0):
+    for mode in (3, 1, 0):
         f = cls(Y, X)
         f.set_sweep_mode("block", 16)
         f.set_gradient_cache(mode)
@@ -886,7 +886,7 @@ def test_gradient_cache_path_matches_oracle_and_plain_passes(loss, rand):
         stats[mode] = f.cache_stats()
         f.close()
     assert stats[0]["passes"] == 0 and stats[0]["gram_columns"] == 0
-    for mode in (2, 1):
+    for mode in (3,):
         s = stats[mode]
         assert s["passes"] >= 10 and s["settled_visits"] > 5 * s["exact_visits"] > 0, s
         assert s["gram_columns"] >= xo.nnz and s["reference_passes"] <= 3, s
@@ -900,7 +900,7 @@ def test_gradient_cache_follows_new_iterates_new_y_and_cold_starts():
     Y2 = X[:, 100:108] @ rng.standard_normal(8) + rng.standard_normal(2500)
     o = dict(maxIter=3000, optTol=1e-12, randomize=False)
     f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
-    f.set_gradient_cache(2)
+    f.set_gradient_cache(3)
     x, xo = cd.SparseIterate(520), O.SparseIterate(520)
 
     def both(lam, **kw):
@@ -937,4 +937,81 @@ def test_gradient_cache_follows_new_iterates_new_y_and_cold_starts():
     x, xo = cd.SparseIterate(520), O.SparseIterate(520)
     both(0.2)
     both(0.08)
+    f.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CDH_FUZZ_CACHE", "12"))))
+def test_gradient_cache_random_configurations_match_oracle(seed):
+    """Random shapes / losses / penalties / orders / sweep modes, a short warm-started path each, the gradient
+    cache from the first full pass: beta at every lambda against the oracle; duplicates in a caller-made visit
+    list go through the same certificates (cdh_pass with screening level 2)."""
+    rng = np.random.default_rng(5000 + seed)
+    p = int(rng.integers(130, 420))
+    n = int(rng.integers(2 * p, 5 * p))
+    s = int(rng.integers(1, 12))
+    X = np.asfortranarray(rng.standard_normal((n, p)) * rng.uniform(0.3, 3.0, size=p))
+    Y = X[:, :s] @ rng.standard_normal(s) + rng.uniform(0.3, 2.0) * rng.standard_normal(n)
+    sqrt = bool(seed % 3 == 2)
+    mode = MODES[int(rng.integers(0, len(MODES)))]
+    om = rng.uniform(0.5, 2.0, size=p) if rng.integers(0, 2) else None
+    o = dict(maxIter=5000, optTol=1e-11, randomize=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)))
+    if sqrt:
+        f, fo = cd.CDSqrtLassoLoss(Y, X), O.CDSqrtLassoLoss(Y, X)
+        top = 0.9 * float(np.max(np.abs(X.T @ Y) / (om if om is not None else 1.0)) / np.linalg.norm(Y))
+        top = min(top, 0.5 * float(np.sqrt(np.min(np.sum(X * X, axis=0)))))
+        lams = top * np.array([1.0, 0.9, 0.8, 0.72, 0.65])
+    else:
+        f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+        top = 0.8 * float(np.max(np.abs(X.T @ Y) / (om if om is not None else 1.0)) / n)
+        lams = top * np.array([1.0, 0.6, 0.35, 0.2, 0.12])
+    _set_mode(f, mode)
+    f.set_gradient_cache(3)
+    x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+    for lam in lams:
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(**o))
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam, om), O.CDOptions(**o))
+        if not st["converged"]:
+            pytest.skip("oracle did not converge at this draw")
+        if xo.nnz * 4 > p:
+            break                                       # dense iterate: full passes are no longer screened
+        scale = max(1.0, float(np.max(np.abs(xo.dense()))))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL * scale,
+                                   err_msg=f"n={n} p={p} sqrt={sqrt} mode={mode} lam={lam}")
+        assert sorted(x.nzval2ind.tolist()) == sorted(xo.nzval2ind.tolist())
+    assert f.cache_stats()["passes"] > 0
+    # a caller-made visit list with repeats, through cdh_pass with screening level 2
+    f.set_screening(2)
+    visit = [int(v) for v in rng.integers(1, p + 1, size=2 * p + 5)]
+    lam = float(lams[1])
+    for _ in range(2):
+        mh, mho = cd.cdPass_(x, f, cd.ProxL1(lam, om), visit), O.cdPass_(xo, fo, O.ProxL1(lam, om), visit)
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(mh, mho, rtol=1e-6, atol=1e-12)
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist()
+    np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-8 * max(1.0, float(np.max(np.abs(Y)))))
+
+
+def test_gradient_cache_default_mode_engages_on_tall_problems_only():
+    """The default (mode 1): rent-or-buy, and only where folding a move into the cached gradient (p host flops)
+    is cheaper than re-reading X (n >= 400 nnz).  A tall path engages it and matches the oracle; the
+    reference's own short-and-wide benchmark shape (n < p) never does."""
+    rng, X, Y = _problem(61, 40_000, 256, 6, noise=1.0)
+    lams = 0.5 * np.exp(np.linspace(0.0, np.log(0.05), 8))
+    o = dict(maxIter=2000, optTol=1e-10, randomize=False)
+    f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+    x, xo = cd.SparseIterate(256), O.SparseIterate(256)
+    for lam in lams:
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"]
+    cs = f.cache_stats()
+    assert xo.nnz * 400 < 40_000 and cs["passes"] >= 5 and cs["reference_passes"] == 1 and cs["gram_columns"] >= xo.nnz, cs
+    f.close()
+    rng, X, Y = _problem(62, 300, 900, 10)
+    f = cd.CDLeastSquaresLoss(Y, X)
+    x = cd.SparseIterate(900)
+    for lam in (0.5, 0.3, 0.2, 0.15, 0.1, 0.08):
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+    assert x.nnz > 1 and f.cache_stats()["passes"] == 0 and f.cache_stats()["gram_columns"] == 0
     f.close()

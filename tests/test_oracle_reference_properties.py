@@ -306,3 +306,42 @@ def test_orthogonal_design_closed_form():
         # the state machine of coordinate_descent.jl:65-92: full pass (moves), active pass
         # (nothing moves -> converged), full pass (still converged -> stop)
         assert st["passes"] == 3 and st["full_passes"] == 2
+
+
+# -- optimality certificates, independent of any solver ---------------------------------------------
+# The reference holds no golden vector for the sqrt-lasso closed form (cd_differentiable_function.jl:
+# 271-283) or for the weighted losses: its tests assert one aggregate KKT number (test/lasso.jl:123, 54).
+# The FULL KKT system of a convex problem is a certificate of optimality on its own: a point that meets
+# it is a minimiser (the minimiser, X having full column rank), whatever produced it.  So the oracle's
+# fixed points are pinned here coordinate by coordinate: gradient = lambda * omega_k * sign(beta_k) on
+# the support, |gradient| <= lambda * omega_k off it.
+@pytest.mark.parametrize("loss", ["ls", "wls", "sqrt"])
+@pytest.mark.parametrize("weighted", [False, True], ids=["l1", "weighted_l1"])
+def test_fixed_points_satisfy_the_full_kkt_system(loss, weighted):
+    rng = np.random.default_rng(71 + 3 * weighted)
+    n, p, s = 600, 80, 9
+    X, Y = _problem(rng, n, p, s)
+    X = np.asfortranarray(X * rng.uniform(0.4, 2.5, size=p))
+    om = rng.uniform(0.5, 2.0, size=p) if weighted else np.ones(p)
+    w = rng.uniform(0.3, 2.0, size=n)
+    lam = {"ls": 0.08, "wls": 0.08, "sqrt": 2.2}[loss]
+    f = {"ls": lambda: O.CDLeastSquaresLoss(Y, X), "wls": lambda: O.CDWeightedLSLoss(Y, X, w),
+         "sqrt": lambda: O.CDSqrtLassoLoss(Y, X)}[loss]()
+    x = O.SparseIterate(p)
+    st = O.coordinateDescent_(x, f, O.ProxL1(lam, om if weighted else None),
+                              O.CDOptions(maxIter=20000, optTol=1e-13, randomize=False))
+    assert st["converged"]
+    b = x.dense()
+    r = Y - X @ b
+    np.testing.assert_allclose(f.r, r, rtol=0, atol=1e-10)          # the carried residual is y - X beta
+    if loss == "ls":
+        grad = X.T @ r / n                      # -grad f; f = |r|^2 / (2n)     (:38-42)
+    elif loss == "wls":
+        grad = X.T @ (w * r) / n                # f = sum w r^2 / (2n)          (:113-117)
+    else:
+        grad = X.T @ r / np.linalg.norm(r)      # f = |r|_2                     (:234-235, test/lasso.jl:123)
+    act = b != 0
+    assert 3 <= act.sum() < p
+    np.testing.assert_allclose(grad[act], lam * om[act] * np.sign(b[act]), rtol=0, atol=1e-9)
+    assert np.all(np.abs(grad[~act]) <= lam * om[~act] * (1 + 1e-9))
+    assert np.linalg.matrix_rank(X[:, act]) == act.sum()            # hence THE minimiser
