@@ -147,6 +147,39 @@ def cfg1_cpu_vs_gpu(device=0):
             "max_abs_beta_diff": float(np.max(np.abs(xg.dense() - xo.dense()))), "tolerance": 1e-10}
 
 
+def cfg3_path(device=0, n=2_000_000, p=5000, nlam=100):
+    """BASELINE.json configs[2] on one GPU (a parity-test case timed for context, never part of `value`):
+    warm-started 100-lambda Lasso path, n = 2e6, p = 5000 (80 GB generated in HBM), omega = _stdX!, ordered
+    sweeps, optTol 1e-7, log-spaced lambdas from lambda_max to 1e-2 lambda_max -- the loop of LassoPath
+    (src/lasso.jl:250-252) as coordinatedescent_jl_amd.LassoPath runs it (carried residual reused, gradient
+    cache from the first full pass).  Its parity and properties are tests/test_gpu_configs.py."""
+    import numpy as np
+    import coordinatedescent_jl_amd as cd
+    f, _ = cd.CDLeastSquaresLoss.generate(n, p, seed=123, s=100, noise=6.0, device=device)
+    try:
+        x = cd.SparseIterate(p)
+        cd.initialize_(f, x)
+        om = cd.stdX(f)
+        lmax = cd.findLambdaMax(x, f, cd.ProxL1(1.0, om))
+        lams = np.exp(np.linspace(np.log(lmax), np.log(1e-2 * lmax), nlam))
+        opt = cd.CDOptions(optTol=1e-7, randomize=False)
+        cd._lib.check(f._L.cdh_set_reuse_residual(f._h, 1), f._h)
+        f.set_gradient_cache(2)
+        f._L.cdh_synchronize(f._h)
+        t0 = time.perf_counter()
+        passes = visits = 0
+        for lam in lams:
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), opt)
+            passes += f.last_stats["passes"]
+            visits += f.last_stats["visits"]
+        f._L.cdh_synchronize(f._h)
+        dt = time.perf_counter() - t0
+        return {"workload": f"lasso_path_{nlam}_lambdas_n{n}_p{p}_f64_warm_started", "seconds": dt, "passes": passes,
+                "visits": visits, "visits_per_sec": visits / dt, "nnz_last": int(x.nnz), "gradient_cache": f.cache_stats()}
+    finally:
+        f.close()
+
+
 def adopt_direct_exchange(mode, selftest_ok, all_ranks_completed, max_abs_dbeta, t_direct, t_rccl):
     """--exchange auto: the direct exchange's timing becomes `value` only if it validated in this very
     run (self-test on every rank, every rank completed the K steps, beta within 1e-9 of the RCCL
@@ -183,6 +216,7 @@ def main():
     ap.add_argument("--no-exchange-trial", action="store_true",
                     help="with --exchange auto: skip the second region (same as --exchange rccl)")
     ap.add_argument("--no-cfg1", action="store_true", help="skip the cfg1 (n=1000, p=200) CPU-vs-GPU solve timing")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg3 (100-lambda path, n=2e6, p=5000) timing")
     a = ap.parse_args()
 
     import numpy as np
@@ -428,9 +462,15 @@ def main():
             res["cfg1"] = cfg1_cpu_vs_gpu(device)
         except Exception as e:
             res["cfg1"] = {"error": str(e)[:200]}
+    f.close()
+    default_workload = (a.rows, a.cols, a.dtype) == (10_000_000, 1000, "f64")
+    if cp.rank == 0 and cp.world == 1 and default_workload and not a.no_cfg3 and not a.no_cpu_baseline:
+        try:                               # the 80 GB of cfg2 are released: cfg3's 80 GB fit
+            res["cfg3_path"] = cfg3_path(device)
+        except Exception as e:
+            res["cfg3_path"] = {"error": str(e)[:200]}
     if cp.rank == 0:
         print(json.dumps(res), flush=True)
-    f.close()
     cp.shutdown()
 
 

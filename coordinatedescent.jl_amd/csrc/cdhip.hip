@@ -685,248 +685,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     return CDH_OK;
 }
 
-// ---- gradient cache: the certified full pass -------------------------------------------------------------
-int32_t gc_size(cdh_handle h) {   // first use on this handle
-    GradCache& c = h->gc;
-    if (!c.g.empty()) return CDH_OK;
-    const size_t p = (size_t)h->p;
-    c.g.assign(p, 0.0); c.a.assign(p, 0.0); c.dbeta.assign(p, 0.0);
-    c.in_moved.assign(p, 0); c.slot.assign(p, -1);
-    c.beta_ref.assign(p, 0.0);
-    c.beta_ok = h->r_consistent;          // r == y - X * (the handle's iterate) right now?
-    if (c.beta_ok)
-        for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) c.beta_ref[(size_t)h->x.coord(s_)] = h->x.slot_value(s_);
-    const int64_t launches = (h->p + kCrossA - 1) / kCrossA;
-    HIPCHK(h, hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec));
-    HIPCHK(h, hipMalloc((void**)&c.d_cols, sizeof(int64_t) * (p + kCrossA + kCrossB)));
-    std::vector<int64_t> ident(p + kCrossA + kCrossB, 0);
-    for (size_t k = 0; k < p; ++k) ident[k] = (int64_t)k;
-    HIPCHK(h, hipMemcpy(c.d_cols, ident.data(), sizeof(int64_t) * ident.size(), hipMemcpyHostToDevice));
-    c.h_cross.assign((size_t)launches * kCrossRec, 0.0);
-    return CDH_OK;
-}
-
-// g = X'r and a = diag(X'X) from one dots-only pass over all of X: the new reference point
-int32_t gc_validate(cdh_handle h) {
-    GradCache& c = h->gc;
-    CHK(col_dots(h, 0, h->p, h->r, false));
-    std::vector<double> cd((size_t)(2 * h->p));
-    HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * h->p, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int64_t k = 0; k < h->p; ++k) { c.g[(size_t)k] = cd[(size_t)(2 * k)]; c.a[(size_t)k] = cd[(size_t)(2 * k + 1)]; }
-    for (int64_t j : c.moved) { c.dbeta[(size_t)j] = 0.0; c.in_moved[(size_t)j] = 0; }
-    c.moved.clear();
-    c.valid = true;
-    c.n_validate += 1;
-    return CDH_OK;
-}
-
-// Gram columns G_j = X'X_j for the coordinates in `cols` (those not cached yet), up to 32 per pass over X
-int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
-    GradCache& c = h->gc;
-    std::vector<int64_t> todo;
-    for (int64_t j : cols) if (c.slot[(size_t)j] < 0 && std::find(todo.begin(), todo.end(), j) == todo.end()) todo.push_back(j);
-    if (todo.empty()) return CDH_OK;
-    if ((c.G.size() + todo.size()) * (size_t)h->p * sizeof(double) > kGcMaxBytes) {
-        gc_invalidate(h, true);
-        c.mode = 0;                       // this problem's supports do not fit: plain screens from now on
-        return CDH_OK;
-    }
-    const int64_t launches = (h->p + kCrossA - 1) / kCrossA;
-    const int G = NGgrid(h, 4);
-    if ((size_t)G * kCrossRec > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partial buffer too small for the cross-product grid");
-    for (size_t b0 = 0; b0 < todo.size(); b0 += kCrossB) {
-        const int nbc = (int)std::min<size_t>(kCrossB, todo.size() - b0);
-        int64_t* d_b = c.d_cols + h->p + kCrossA;
-        HIPCHK(h, hipMemcpyAsync(d_b, todo.data() + b0, sizeof(int64_t) * (size_t)nbc, hipMemcpyHostToDevice, h->stream));
-        for (int64_t L = 0; L < launches; ++L) {
-            const int na = (int)std::min<int64_t>(kCrossA, h->p - L * kCrossA);
-            CHK(dispatch(h, [&](auto* t) {
-                using T = std::remove_pointer_t<decltype(t)>;
-                hipLaunchKernelGGL(k_cross<T>, dim3(G), dim3(64 * kGramWaves), 0, h->stream, (const T*)h->X, h->ld, h->nvec,
-                                   c.d_cols + L * kCrossA, na, d_b, nbc, h->d_partials);
-                return CDH_OK;
-            }));
-            hipLaunchKernelGGL(k_gram_reduce, dim3(kCrossRec / kReduceVals), dim3(64 * kReduceWaves), 0, h->stream,
-                               h->d_partials, G, kCrossRec, c.d_cross + L * kCrossRec);
-        }
-        HIPCHK(h, hipGetLastError());
-        CHK(allreduce(h, c.d_cross, (size_t)launches * kCrossRec));
-        HIPCHK(h, hipMemcpyAsync(c.h_cross.data(), c.d_cross, sizeof(double) * (size_t)launches * kCrossRec,
-                                 hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));   // also: todo[b0 ..] has been consumed
-        for (int b = 0; b < nbc; ++b) {
-            c.G.emplace_back((size_t)h->p, 0.0);
-            std::vector<double>& col = c.G.back();
-            for (int64_t k = 0; k < h->p; ++k) {
-                const int64_t L = k / kCrossA, i = k % kCrossA;
-                col[(size_t)k] = c.h_cross[(size_t)(L * kCrossRec + ((i >> 4) * kCrossTB + (b >> 4)) * 256 + (i & 15) * 16 + (b & 15))];
-            }
-            c.slot[(size_t)todo[b0 + (size_t)b]] = (int32_t)(c.G.size() - 1);
-        }
-        c.n_batches += 1; c.n_columns += nbc;
-    }
-    return CDH_OK;
-}
-
-// g <- g - sum_j dbeta_j G_j over the pending moves (all of which must have their columns)
-void gc_fold(cdh_handle h) {
-    GradCache& c = h->gc;
-    for (int64_t j : c.moved) {
-        const double d = c.dbeta[(size_t)j];
-        const std::vector<double>& col = c.G[(size_t)c.slot[(size_t)j]];
-        if (d != 0.0)
-            for (int64_t k = 0; k < h->p; ++k) c.g[(size_t)k] -= d * col[(size_t)k];
-        c.dbeta[(size_t)j] = 0.0; c.in_moved[(size_t)j] = 0;
-    }
-    c.moved.clear();
-}
-
-int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH);
-
-// A full pass over idx0[0..m) from the cache.  *handled = false: the caller runs the pass the plain way.
-int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, bool* handled) {
-    GradCache& c = h->gc;
-    *handled = false;
-    c.full_seen += 1;
-    // mode 1 buys the Gram columns of the support (1.5 passes over X per 32 of them) only after the handle has
-    // paid that much in plain full passes on the same data: at most twice the cost of having known in advance
-    const int64_t rent = std::max<int64_t>(kGcEngage, 1 + (3 * h->x.nnz()) / 64);
-    if (!gc_applicable(h) || (c.mode == 1 && !c.valid && c.full_seen <= rent)) return CDH_OK;
-    // Folding a moved coordinate into g is p host flops (~0.5 ns each); reading X once is n p sz bytes at
-    // ~6 TB/s.  The cache only pays while nnz * p * 0.5 ns stays well under that, i.e. for n >> 400 nnz:
-    // short-and-wide problems (the reference's own n = 3000, p = 5000 shape) keep the dots-only screens.
-    if (c.mode != 3 && h->x.nnz() * kGcRowsPerNnz > h->n_total) {
-        if (c.valid) gc_invalidate(h, false);
-        return CDH_OK;
-    }
-    if (h->x.nnz() > kGcMaxSupport) return CDH_OK;
-    if (c.cooldown > 0) { c.cooldown -= 1; if (c.valid) gc_invalidate(h, false); return CDH_OK; }
-    CHK(gc_size(h));
-    if (c.mode == 0) return CDH_OK;
-    const double lam = h->ctrl.lambda0, nt = (double)h->n_total;
-    const std::vector<double>& om = h->h_omega;
-    // 1. a current g: fold the pending moves, fetching the columns that are missing; too many missing (or no
-    //    reference yet): one dots-only pass over X gives a fresh g instead
-    std::vector<int64_t> want;
-    if (c.valid) {
-        for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) want.push_back(j);
-        if ((int)want.size() > kGcMaxFetch) { gc_invalidate(h, false); want.clear(); }
-    }
-    if (!c.valid) {
-        const bool ok = c.beta_ok;
-        std::vector<double> keep;
-        if (ok) keep = c.beta_ref;
-        CHK(gc_validate(h));
-        c.beta_ok = ok;
-        if (ok) c.beta_ref.swap(keep);
-    }
-    for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_)       // the support moves in every pass: its columns first
-        if (c.slot[(size_t)h->x.coord(s_)] < 0) want.push_back(h->x.coord(s_));
-    double rnorm = 0.0;
-    auto refresh_rnorm = [&]() -> int32_t {
-        if (h->loss != CDH_SQRT) return CDH_OK;
-        CHK(resid_moments_dev(h));
-        HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        rnorm = std::sqrt(h->h_red[1]);
-        return CDH_OK;
-    };
-    auto thr_of = [&](int64_t k) {
-        const double w = h->has_omega ? om[(size_t)k] : 1.0;
-        return (h->loss == CDH_SQRT ? lam * w * rnorm : lam * nt * w) * (1.0 - 1e-9);
-    };
-    // settled = the exact visit would leave beta_k at zero and r untouched (zero columns take the exact path)
-    auto settled = [&](int64_t k) {
-        return h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0 && std::fabs(c.g[(size_t)k]) <= thr_of(k);
-    };
-    if (!want.empty()) {
-        // fill the last batch of 32 with the inactive coordinates nearest their threshold: the likeliest to
-        // enter the support next (on a lambda path: at one of the next lambdas)
-        const size_t room = (kCrossB - want.size() % kCrossB) % kCrossB;
-        if (room > 0 && c.moved.empty()) {
-            CHK(refresh_rnorm());
-            std::vector<std::pair<double, int64_t>> near;
-            for (int64_t k = 0; k < h->p; ++k)
-                if (c.slot[(size_t)k] < 0 && h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0)
-                    near.emplace_back(std::fabs(c.g[(size_t)k]) / thr_of(k), k);
-            const size_t take = std::min(room, near.size());
-            std::partial_sort(near.begin(), near.begin() + (std::ptrdiff_t)take, near.end(), std::greater<std::pair<double, int64_t>>());
-            for (size_t i = 0; i < take; ++i) want.push_back(near[i].second);
-        }
-        CHK(gc_fetch(h, want));
-        if (c.mode == 0) return CDH_OK;
-    }
-    for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return fail(h, CDH_BAD_ARG, "gradient cache: a moved coordinate has no Gram column");
-    gc_fold(h);
-    CHK(refresh_rnorm());
-    // 2. inactive coordinates about to move: many of them means the pass is mostly real visits anyway
-    std::vector<int64_t> enter;
-    for (int64_t i = 0; i < m; ++i) {
-        const int64_t k = idx0[i];
-        if (h->x.get(k) == 0.0 && !settled(k) && c.slot[(size_t)k] < 0) enter.push_back(k);
-    }
-    std::sort(enter.begin(), enter.end());
-    enter.erase(std::unique(enter.begin(), enter.end()), enter.end());
-    if ((int)enter.size() > kGcBusy) {   // busy: back off (1, 2, 4 ... 16 plain passes) so that dense problems pay next to nothing
-        c.cooldown = c.backoff; c.backoff = std::min(16, 2 * c.backoff);
-        gc_invalidate(h, false);
-        return CDH_OK;
-    }
-    c.backoff = 1;
-    if (!enter.empty()) {
-        // their columns now, with the nearest other candidates filling the batch
-        const size_t room = (kCrossB - enter.size() % kCrossB) % kCrossB;
-        std::vector<std::pair<double, int64_t>> near;
-        for (int64_t k = 0; k < h->p && room > 0; ++k)
-            if (c.slot[(size_t)k] < 0 && h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0 && settled(k))
-                near.emplace_back(std::fabs(c.g[(size_t)k]) / thr_of(k), k);
-        const size_t take = std::min(room, near.size());
-        std::partial_sort(near.begin(), near.begin() + (std::ptrdiff_t)take, near.end(), std::greater<std::pair<double, int64_t>>());
-        for (size_t i = 0; i < take; ++i) enter.push_back(near[i].second);
-        CHK(gc_fetch(h, enter));
-        if (c.mode == 0) return CDH_OK;
-    }
-    *handled = true;
-    c.n_passes += 1;
-    // 3. the walk: runs of settled visits are skipped (with the bookkeeping the reference's SparseIterate
-    //    would have seen); everything else is visited by the ordinary kernels, a few visits per chunk
-    const int B = (h->mode == CDH_SWEEP_BLOCK) ? h->blockB : 1;
-    const int64_t maxlen = std::min<int64_t>(h->cap, std::max<int64_t>(4 * B, 64));
-    int64_t pos = 0;
-    while (pos < m) {
-        const int64_t k = idx0[pos];
-        if (settled(k)) {
-            if (h->loss != CDH_SQRT && c.g[(size_t)k] != 0.0) h->x.set(k, 1.0);   // x[k] += b/a stores a slot ...
-            h->x.set(k, 0.0);                                                          // ... cdprox! zeroes it
-            c.n_certified += 1;
-            ++pos;
-            continue;
-        }
-        // exact visits [pos, end): up to the last unsettled position that is no more than 4 past the previous one
-        int64_t end = pos + 1;
-        for (int64_t q = pos + 1; q < m && q - end < 4 && end - pos < maxlen; ++q)
-            if (!settled(idx0[q])) end = q + 1;
-        CHK(run_chunk(h, idx0 + pos, (int)(end - pos), maxH));
-        c.n_exact += end - pos;
-        pos = end;
-        if (!c.valid) { *handled = true; break; }     // a NaN step: finish below the plain way
-        if (!c.moved.empty()) {
-            std::vector<int64_t> miss;
-            for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) miss.push_back(j);
-            if (!miss.empty()) { CHK(gc_fetch(h, miss)); if (c.mode == 0) break; }
-            gc_fold(h);
-            CHK(refresh_rnorm());
-        }
-    }
-    if (pos < m) {   // the cache went away mid-pass: the rest of the list the plain way, chunk by chunk
-        for (int64_t off = pos; off < m; off += h->cap) {
-            const int mm = (int)std::min<int64_t>(h->cap, m - off);
-            CHK(run_chunk(h, idx0 + off, mm, maxH));
-        }
-    }
-    return CDH_OK;
-}
+#include "grad_cache.hpp"   // gc_size, gc_validate, gc_fetch, gc_fold, gc_full_pass
 
 // _cdPass! (coordinate_descent.jl:94-110)
 // Screening of a FULL pass (exact, no reference counterpart).  A visit of a coordinate with

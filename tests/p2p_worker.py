@@ -123,6 +123,15 @@ def main():
                 raise AssertionError("a lone rank's exchange must time out")
             except cd._lib.HipError as e:
                 assert ("timed out" if attempt == 0 else "lost its exchange") in str(e), str(e)
+        # ... in EVERY sweep mode: the per-coordinate and narrow-block sweeps must not fall into the
+        # single-process kernels on their local rows and return numbers
+        for mode, block in (("coord", 8), ("block", 8), ("block", 32)):
+            f.set_sweep_mode(mode, block)
+            try:
+                cd.cdPass_(cd.SparseIterate(p), f, cd.ProxL1(0.1), [1, 2, 3])
+                raise AssertionError(f"a shard without its exchange swept anyway ({mode}{block})")
+            except cd._lib.HipError as e:
+                assert "lost its exchange" in str(e), str(e)
     cp.barrier()
     del f
     if cp.rank == 0:

@@ -29,6 +29,8 @@ def cfg3(n=2_000_000, p=5000, nlam=100):
     lmax = cd.findLambdaMax(x, f, cd.ProxL1(1.0, om))
     lams = np.exp(np.linspace(np.log(lmax), np.log(1e-2 * lmax), nlam))
     opt = cd.CDOptions(optTol=1e-7, randomize=False)
+    # what cd.LassoPath does around its loop: the carried residual is reused by the warm starts
+    cd._lib.check(f._L.cdh_set_reuse_residual(f._h, int(os.environ.get("CFG_REUSE", "1"))), f._h)
     t0 = time.perf_counter()
     passes = visits = 0
     nnz = []
