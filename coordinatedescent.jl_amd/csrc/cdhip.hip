@@ -895,6 +895,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->nt = env_int("CDH_NT", 1) != 0;
         h->lt = env_int("CDH_LT", 2);
         h->ks = env_int("CDH_KS", 0);
+        h->gc.mode = std::max(0, std::min(3, env_int("CDH_GRADIENT_CACHE", 1)));
         const int step_per_cu = std::max(1, env_int("CDH_STEP_GRID_PER_CU", 8));
         const int block_per_cu = std::max(1, std::min(kBlockGridPerCU, env_int("CDH_BLOCK_GRID_PER_CU", 3)));
         const int64_t want = (h->nvec + (int64_t)kBlock * kUnroll - 1) / ((int64_t)kBlock * kUnroll);

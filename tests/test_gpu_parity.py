@@ -999,6 +999,7 @@ def test_gradient_cache_default_mode_engages_on_tall_problems_only():
     lams = 0.5 * np.exp(np.linspace(0.0, np.log(0.05), 8))
     o = dict(maxIter=2000, optTol=1e-10, randomize=False)
     f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+    f.set_gradient_cache(1)                      # the default, whatever CDH_GRADIENT_CACHE says
     x, xo = cd.SparseIterate(256), O.SparseIterate(256)
     for lam in lams:
         cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
@@ -1010,6 +1011,7 @@ def test_gradient_cache_default_mode_engages_on_tall_problems_only():
     f.close()
     rng, X, Y = _problem(62, 300, 900, 10)
     f = cd.CDLeastSquaresLoss(Y, X)
+    f.set_gradient_cache(1)
     x = cd.SparseIterate(900)
     for lam in (0.5, 0.3, 0.2, 0.15, 0.1, 0.08):
         cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
