@@ -292,10 +292,10 @@ class _HipLoss(CoordinateDifferentiableFunction):
         check(self._L.cdh_set_gradient_cache(self._h, int(mode)), self._h)
 
     def cache_stats(self):
-        out = (C.c_int64 * 6)()
+        out = (C.c_int64 * 9)()
         check(self._L.cdh_cache_stats(self._h, out), self._h)
-        return dict(zip(("passes", "settled_visits", "exact_visits", "reference_passes", "gram_batches", "gram_columns"),
-                        [int(v) for v in out]))
+        return dict(zip(("passes", "settled_visits", "exact_visits", "reference_passes", "gram_batches", "gram_columns",
+                         "covariance_visits", "residual_catchups", "rollbacks"), [int(v) for v in out]))
 
     def set_use_graph(self, on=True):
         check(self._L.cdh_set_use_graph(self._h, int(bool(on))), self._h)

@@ -96,7 +96,16 @@ struct GradCache {
     double* d_cross = nullptr;      // device: ceil(p / 64) records of 64 x 32 cross products
     int64_t* d_cols = nullptr;      // device: 0 .. p-1 (A operand lists) followed by the B columns of a batch
     std::vector<double> h_cross;
-    int64_t n_validate = 0, n_batches = 0, n_columns = 0, n_certified = 0, n_exact = 0, n_passes = 0;
+    // covariance-form visits: device mirrors of g, the Gram columns (slot-major, p doubles each) and the slot map
+    bool cov = true;                // env CDH_GC_COV
+    double *d_g = nullptr, *d_G = nullptr;
+    int32_t* d_slot = nullptr;
+    int64_t dev_slots_cap = 0, dev_slots = 0;   // columns the device store can hold / holds
+    int64_t cov_since_ref = 0;      // covariance-form visits since g was last taken from X itself
+    std::vector<double> g_new;      // g as a covariance-form chunk left it, until the chunk is accepted
+    int64_t n_rollbacks = 0;
+    int64_t n_validate = 0, n_batches = 0, n_columns = 0, n_certified = 0, n_exact = 0, n_passes = 0, n_cov = 0,
+            n_reconcile = 0;
 };
 
 struct cdh_handle_s {
@@ -165,6 +174,10 @@ struct cdh_handle_s {
     int64_t n_rccl_calls = 0, n_p2p_calls = 0, n_host_calls = 0;
     // profile
     GradCache gc;
+    // beta changes the covariance-form visits have made that r has not seen yet: r_actual = r_virtual + X * pending
+    std::vector<double> r_pending;
+    std::vector<int64_t> r_pending_list;
+    std::vector<uint8_t> r_in_pending;
     bool prof = false;
     double prof_ms = 0.0, prof_bytes = 0.0;
     int64_t prof_launches = 0;
@@ -300,9 +313,41 @@ int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
     return CDH_OK;
 }
 
+// ---- r catches up with the covariance-form visits: r -= sum_k pending_k X_k, 64 columns per launch ----------
+// Called by everything that reads r (the streaming kernels, the dots, the moments, the download) and by the
+// entry points that may have run covariance-form chunks, so outside the library r is always y - X beta.
+int32_t sync_r(cdh_handle h) {
+    if (h->r_pending_list.empty()) return CDH_OK;
+    std::vector<int64_t>& L = h->r_pending_list;
+    for (size_t o = 0; o < L.size(); o += 64) {
+        const int cnt = (int)std::min<size_t>(64, L.size() - o);
+        for (int i = 0; i < cnt; ++i) { h->h_idx[i] = L[o + (size_t)i]; h->h_hs[i] = h->r_pending[(size_t)L[o + (size_t)i]]; }
+        HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)cnt, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_hs, h->h_hs, sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice, h->stream));
+        CHK(dispatch(h, [&](auto* t) {
+            using T = std::remove_pointer_t<decltype(t)>;
+            hipLaunchKernelGGL(k_multi_axpy<T>, dim3(h->step_grid), dim3(kBlock), 0, h->stream, (const T*)h->X, h->ld,
+                               h->nvec, (T*)h->r, h->d_idx, h->d_hs, 0, cnt);
+            return CDH_OK;
+        }));
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // the pinned staging arrays are reused
+    }
+    for (int64_t k : L) { h->r_pending[(size_t)k] = 0.0; h->r_in_pending[(size_t)k] = 0; }
+    L.clear();
+    h->gc.n_reconcile += 1;
+    return CDH_OK;
+}
+// r is about to be overwritten from scratch (initialize!, a new y): nothing to catch up with
+inline void drop_r_pending(cdh_handle h) {
+    for (int64_t k : h->r_pending_list) { h->r_pending[(size_t)k] = 0.0; h->r_in_pending[(size_t)k] = 0; }
+    h->r_pending_list.clear();
+}
+
 // ---- column dots over columns [j0, j0+nc): d_colout[2*j + {0,1}] = (x.r (w), x.x (w)) ----
 int32_t col_dots(cdh_handle h, int64_t j0, int64_t nc, const void* rvec, bool use_w,
                  const int64_t* d_cols = nullptr) {
+    if (rvec == h->r) CHK(sync_r(h));
     // batches of at most 4096 columns keep the partial buffer small
     for (int64_t b0 = 0; b0 < nc; b0 += 4096) {
         const int64_t bc = std::min<int64_t>(4096, nc - b0);
@@ -329,6 +374,7 @@ int32_t col_dots(cdh_handle h, int64_t j0, int64_t nc, const void* rvec, bool us
 }
 
 int32_t resid_moments_dev(cdh_handle h) {  // -> d_red[0..2] = sum r, sum r^2, sum w r^2
+    CHK(sync_r(h));
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (h->nvec + kBlock - 1) / kBlock));
     CHK(dispatch(h, [&](auto* t) {
         using T = std::remove_pointer_t<decltype(t)>;
@@ -348,6 +394,8 @@ constexpr int kGcBusy = 64;         // more inactive coordinates than this about
 constexpr int kGcMaxFetch = 64;     // more uncached movers than this: re-reference instead of fetching their columns
 constexpr int kGcMaxSupport = 512;  // supports beyond this are not worth Gram columns
 constexpr size_t kGcMaxBytes = (size_t)1 << 30;
+constexpr int64_t kGcCovWindow = 2048;      // positions one covariance-form chunk of a full pass may span
+constexpr int64_t kGcCovRefresh = 200000;   // covariance-form visits after which g is re-read from X
 constexpr int64_t kGcRowsPerNnz = 400;   // rows the problem must have per non-zero for the host-side fold to pay
 
 inline bool gc_applicable(const cdh_handle_s* h) {
@@ -362,6 +410,7 @@ void gc_invalidate(cdh_handle h, bool columns) {
     if (columns) {
         c.G.clear(); c.G.shrink_to_fit();
         std::fill(c.slot.begin(), c.slot.end(), -1);
+        c.dev_slots = 0;                 // the device store is refilled from slot 0 (its memory is kept)
         c.full_seen = 0;
     }
 }
@@ -385,7 +434,7 @@ void gc_after_rebuild(cdh_handle h) {
     c.beta_ref.swap(nb);
     c.beta_ok = true;
 }
-// the visits of a chunk have been applied to r: remember what moved
+// the streamed visits of a chunk have updated r: g learns of them at the next fold
 void gc_note_moves(cdh_handle h, const int64_t* idx0, int m) {
     GradCache& c = h->gc;
     if (!c.valid && !c.beta_ok) return;
@@ -404,6 +453,7 @@ void gc_note_moves(cdh_handle h, const int64_t* idx0, int m) {
 
 // ---- initialize!: upload support, r = y - X beta ------------------------------------
 int32_t rebuild_residual(cdh_handle h) {
+    drop_r_pending(h);
     const int64_t nnz = h->x.nnz();
     if (nnz == 0) {   // the cold start: beta = 0, r = y; nothing host-side is in flight, so no wait either
         HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
@@ -433,6 +483,39 @@ int32_t rebuild_residual(cdh_handle h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors above go out of scope
     h->r_consistent = true;
     gc_after_rebuild(h);
+    return CDH_OK;
+}
+
+// does any coordinate repeat in the chunk?  (scheduler-made lists never do; caller-made ones may)
+void note_duplicates(cdh_handle h, const int64_t* idx0, int m) {
+    if ((int64_t)h->stamp.size() != h->p) h->stamp.assign((size_t)h->p, 0);
+    h->chunk_dup = false;
+    for (int i = 0; i < m; ++i) {
+        if (h->stamp[(size_t)idx0[i]]) { h->chunk_dup = true; break; }
+        h->stamp[(size_t)idx0[i]] = 1;
+    }
+    for (int i = 0; i < m; ++i) h->stamp[(size_t)idx0[i]] = 0;
+}
+
+// The visits of a chunk have been enqueued (streamed, or in covariance form): bring their results back,
+// replay them on the host-side SparseIterate, and tell the gradient cache what moved.
+int32_t finish_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
+    HIPCHK(h, hipMemcpyAsync(h->h_hs, h->d_hs, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_newval, h->d_newval, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_touched, h->d_touched, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    CHK(p2p_check(h));
+    if (h->h_ctrl->domain_error) h->domain_error = true;
+    const double mh = h->h_ctrl->maxH;
+    if (mh > *maxH) *maxH = mh;   // a NaN h never raises maxH: `abs(h) > maxH` (coordinate_descent.jl:104)
+    // replay the SparseIterate writes of the visits in order (x[k] += b/a ; cdprox!)
+    for (int i = 0; i < m; ++i) {
+        const int64_t k = idx0[i];
+        if (h->h_touched[i] && h->x.get(k) == 0.0) h->x.set(k, 1.0);  // pre-prox non-zero: slot appended
+        h->x.set(k, h->h_newval[i]);
+    }
+    gc_note_moves(h, idx0, m);
     return CDH_OK;
 }
 
@@ -559,16 +642,9 @@ template <typename T> int32_t launch_coord_chunk(cdh_handle h, int m) {
 }
 
 int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
+    CHK(sync_r(h));   // the streaming kernels read and write r
     std::memcpy(h->h_idx, idx0, sizeof(int64_t) * (size_t)m);
-    {   // does any coordinate repeat?  (scheduler-made lists never do; caller-made ones may)
-        if ((int64_t)h->stamp.size() != h->p) h->stamp.assign((size_t)h->p, 0);
-        h->chunk_dup = false;
-        for (int i = 0; i < m; ++i) {
-            if (h->stamp[(size_t)idx0[i]]) { h->chunk_dup = true; break; }
-            h->stamp[(size_t)idx0[i]] = 1;
-        }
-        for (int i = 0; i < m; ++i) h->stamp[(size_t)idx0[i]] = 0;
-    }
+    note_duplicates(h, idx0, m);
     HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
     h->ctrl.maxH = 0.0;
     h->ctrl.domain_error = 0;
@@ -640,22 +716,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     if (!launched) CHK(enqueue());
     HIPCHK(h, hipGetLastError());
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_hs, h->d_hs, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_newval, h->d_newval, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_touched, h->d_touched, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    CHK(p2p_check(h));
-    if (h->h_ctrl->domain_error) h->domain_error = true;
-    const double mh = h->h_ctrl->maxH;
-    if (mh > *maxH) *maxH = mh;   // a NaN h never raises maxH: `abs(h) > maxH` (coordinate_descent.jl:104)
-    // replay the SparseIterate writes of the visits in order (x[k] += b/a ; cdprox!)
-    for (int i = 0; i < m; ++i) {
-        const int64_t k = idx0[i];
-        if (h->h_touched[i] && h->x.get(k) == 0.0) h->x.set(k, 1.0);  // pre-prox non-zero: slot appended
-        h->x.set(k, h->h_newval[i]);
-    }
-    gc_note_moves(h, idx0, m);
+    CHK(finish_chunk(h, idx0, m, maxH));
     if (h->prof) {
         float ms = 0.f;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -771,7 +832,9 @@ int32_t run_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, boo
     } else {
         for (int64_t off = 0; off < m; off += h->cap) {
             const int mm = (int)std::min<int64_t>(h->cap, m - off);
-            CHK(run_chunk(h, idx0 + off, mm, maxH));
+            // an active pass while the gradient cache holds the support's Gram columns: no read of X at all
+            if (gc_ready_for_cov(h, idx0 + off, mm)) CHK(cov_chunk(h, idx0 + off, mm, maxH));
+            else CHK(run_chunk(h, idx0 + off, mm, maxH));
         }
     }
     h->x.dropzeros();
@@ -830,6 +893,9 @@ void free_all(cdh_handle h) {
     if (h->d_p2p_base) (void)hipFree(h->d_p2p_base);
     if (h->gc.d_cross) (void)hipFree(h->gc.d_cross);
     if (h->gc.d_cols) (void)hipFree(h->gc.d_cols);
+    if (h->gc.d_g) (void)hipFree(h->gc.d_g);
+    if (h->gc.d_G) (void)hipFree(h->gc.d_G);
+    if (h->gc.d_slot) (void)hipFree(h->gc.d_slot);
     if (h->h_xchg) (void)hipHostFree(h->h_xchg);
     if (h->p2p_timeout) (void)hipHostFree(h->p2p_timeout);
     for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);
@@ -882,6 +948,8 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
     h->nvec = round_up(n_local, NV) / NV;     // pad rows [n, ld) are zero in X, y, r, w
     h->cap = std::max<int64_t>(p, 4096);
     h->x.resize(p);
+    h->r_pending.assign((size_t)p, 0.0);
+    h->r_in_pending.assign((size_t)p, 0);
     int32_t rc = [&]() -> int32_t {
         HIPCHK(h, hipSetDevice(device));
         HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -896,6 +964,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->lt = env_int("CDH_LT", 2);
         h->ks = env_int("CDH_KS", 0);
         h->gc.mode = std::max(0, std::min(3, env_int("CDH_GRADIENT_CACHE", 1)));
+        h->gc.cov = env_int("CDH_GC_COV", 1) != 0;
         const int step_per_cu = std::max(1, env_int("CDH_STEP_GRID_PER_CU", 8));
         const int block_per_cu = std::max(1, std::min(kBlockGridPerCU, env_int("CDH_BLOCK_GRID_PER_CU", 3)));
         const int64_t want = (h->nvec + (int64_t)kBlock * kUnroll - 1) / ((int64_t)kBlock * kUnroll);
@@ -973,6 +1042,10 @@ int32_t cdh_synchronize(cdh_handle h) {
 int32_t cdh_set_X_cols(cdh_handle h, int64_t j0, int64_t ncols, const void* host, int64_t ld) {
     NEED_H(h);
     if (ncols > 0) NEED_P(h, host);
+    if (!h->r_pending_list.empty()) {   // r still owes updates in terms of the OLD columns
+        HIPCHK(h, hipSetDevice(h->device));
+        CHK(sync_r(h));
+    }
     h->r_consistent = false;
     gc_invalidate(h, true);
     if (j0 < 0 || ncols < 0 || j0 + ncols > h->p || ld < h->n) return fail(h, CDH_DIM_MISMATCH, "column block outside X");
@@ -1003,6 +1076,7 @@ int32_t cdh_set_y(cdh_handle h, const void* host_y) {
     NEED_P(h, host_y);
     h->r_consistent = false;
     gc_invalidate(h, false);
+    drop_r_pending(h);                 // r = copy(y) below
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(h->y, host_y, (size_t)h->n * h->esz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->r, h->y, (size_t)h->n * h->esz, hipMemcpyDeviceToDevice, h->stream));
@@ -1060,6 +1134,7 @@ int32_t cdh_set_loss(cdh_handle h, int32_t loss) {
 static int32_t cdh_generate_impl(cdh_handle h, uint64_t seed, int64_t s, double noise, double* out_beta_star) {
     if (s < 0 || s > h->p) return fail(h, CDH_BAD_ARG, "need 0 <= s <= p");
     gc_invalidate(h, true);
+    drop_r_pending(h);
     HIPCHK(h, hipSetDevice(h->device));
     // planted coefficients: beta*_j = z_j (1 + u_j) (benchmark/cd_bench.jl:14), stream 2
     std::vector<double> bstar((size_t)std::max<int64_t>(s, 1), 0.0);
@@ -1208,6 +1283,7 @@ static int32_t cdh_pass_impl(cdh_handle h, int64_t m, const int64_t* idx1, doubl
     double maxH = 0.0;
     if (m > 0) CHK(run_pass(h, idx0.data(), m, &maxH, h->screening >= 2));
     else h->x.dropzeros();
+    CHK(sync_r(h));                    // on return r is y - X beta again, whatever form the visits took
     if (out_maxH) *out_maxH = maxH;
     return CDH_OK;
 }
@@ -1218,6 +1294,7 @@ static int32_t cdh_solve_impl(cdh_handle h, const cdh_options* opt, cdh_stats* o
     cdh_stats st{};
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
     int32_t rc = solve(h, opt, sched, &st);
+    if (rc == CDH_OK) rc = sync_r(h);
     if (out) *out = st;
     return rc;
 }
@@ -1261,6 +1338,7 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
             HIPCHK(h, hipStreamSynchronize(h->stream));
         }
     }
+    if (rc == CDH_OK) rc = sync_r(h);
     if (out) *out = st;
     return rc;
 }
@@ -1286,6 +1364,7 @@ int32_t cdh_get_residual(cdh_handle h, void* out_n_local) {
     NEED_H(h);
     NEED_P(h, out_n_local);
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(sync_r(h));
     HIPCHK(h, hipMemcpyAsync(out_n_local, h->r, (size_t)h->n * h->esz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return CDH_OK;
@@ -1320,6 +1399,7 @@ static int32_t cdh_gram_impl(cdh_handle h, int64_t m, const int64_t* idx1, doubl
     for (int64_t i = 0; i < m; ++i)
         if (idx1[i] < 1 || idx1[i] > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(sync_r(h));
     for (int64_t i = 0; i < m; ++i) h->h_idx[i] = idx1[i] - 1;
     HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
     // one k_gramstep launch with no pending update: r is only read
@@ -1409,12 +1489,13 @@ int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode) {
     return CDH_OK;
 }
 
-int32_t cdh_cache_stats(cdh_handle h, int64_t* out6) {
+int32_t cdh_cache_stats(cdh_handle h, int64_t* out9) {
     NEED_H(h);
-    NEED_P(h, out6);
+    NEED_P(h, out9);
     const GradCache& c = h->gc;
-    out6[0] = c.n_passes; out6[1] = c.n_certified; out6[2] = c.n_exact;
-    out6[3] = c.n_validate; out6[4] = c.n_batches; out6[5] = c.n_columns;
+    out9[0] = c.n_passes; out9[1] = c.n_certified; out9[2] = c.n_exact;
+    out9[3] = c.n_validate; out9[4] = c.n_batches; out9[5] = c.n_columns;
+    out9[6] = c.n_cov; out9[7] = c.n_reconcile; out9[8] = c.n_rollbacks;
     return CDH_OK;
 }
 

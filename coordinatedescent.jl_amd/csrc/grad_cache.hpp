@@ -8,6 +8,9 @@
 // 94-99).  No reference counterpart; same iterates.  Design and measurements: DESIGN.md section 5a.
 #pragma once
 
+void gc_fold(cdh_handle h);
+int32_t finish_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH);
+
 // ---- gradient cache: the certified full pass -------------------------------------------------------------
 int32_t gc_size(cdh_handle h) {   // first use on this handle
     GradCache& c = h->gc;
@@ -29,6 +32,140 @@ int32_t gc_size(cdh_handle h) {   // first use on this handle
     return CDH_OK;
 }
 
+// ---- device mirrors for the covariance-form visits ------------------------------------------------------
+// The Gram columns the host holds are mirrored slot-major on the device (p doubles each), with the slot map;
+// g is sent down before a chunk and comes back after it, so the host copy stays the one truth.
+int32_t gc_dev_upload(cdh_handle h) {
+    GradCache& c = h->gc;
+    if (!c.cov) return CDH_OK;
+    const int64_t p = h->p, have = (int64_t)c.G.size();
+    if (!c.d_g) {
+        HIPCHK(h, hipMalloc((void**)&c.d_g, sizeof(double) * (size_t)p));
+        HIPCHK(h, hipMalloc((void**)&c.d_slot, sizeof(int32_t) * (size_t)p));
+    }
+    if (have > c.dev_slots_cap) {   // grow the store (64 columns at a time, at most kGcMaxBytes), keeping what is there
+        const int64_t cap = std::min<int64_t>((have + 63) / 64 * 64 + 64, (int64_t)(kGcMaxBytes / sizeof(double)) / std::max<int64_t>(p, 1));
+        if (cap < have) { c.cov = false; return CDH_OK; }   // does not fit: the visits stay in residual form
+        double* bigger = nullptr;
+        HIPCHK(h, hipMalloc((void**)&bigger, sizeof(double) * (size_t)cap * (size_t)p));
+        if (c.d_G && c.dev_slots > 0)
+            HIPCHK(h, hipMemcpyAsync(bigger, c.d_G, sizeof(double) * (size_t)c.dev_slots * (size_t)p, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (c.d_G) (void)hipFree(c.d_G);
+        c.d_G = bigger; c.dev_slots_cap = cap;
+    }
+    for (int64_t s_ = c.dev_slots; s_ < have; ++s_)
+        HIPCHK(h, hipMemcpyAsync(c.d_G + s_ * p, c.G[(size_t)s_].data(), sizeof(double) * (size_t)p, hipMemcpyHostToDevice, h->stream));
+    c.dev_slots = have;
+    HIPCHK(h, hipMemcpyAsync(c.d_slot, c.slot.data(), sizeof(int32_t) * (size_t)p, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+
+// May visits idx0[0..m) run in covariance form?  Least squares in fp64, a current g with nothing left to
+// fold, and a Gram column on the device for every coordinate of the chunk.
+bool cov_ok(cdh_handle h, const int64_t* idx0, int64_t m) {
+    const GradCache& c = h->gc;
+    if (!c.cov || !c.valid || !c.moved.empty() || h->loss != CDH_LS || !gc_applicable(h) || !c.d_G) return false;
+    if (c.dev_slots != (int64_t)c.G.size()) return false;
+    for (int64_t i = 0; i < m; ++i) if (c.slot[(size_t)idx0[i]] < 0) return false;
+    return true;
+}
+
+// fold what can be folded, then ask cov_ok (the active passes of a solve call this before every chunk)
+bool gc_ready_for_cov(cdh_handle h, const int64_t* idx0, int64_t m) {
+    GradCache& c = h->gc;
+    if (!c.cov || !c.valid || h->loss != CDH_LS || !c.d_G) return false;
+    if (!c.moved.empty()) {
+        for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return false;
+        gc_fold(h);
+    }
+    return cov_ok(h, idx0, m);
+}
+
+
+// Visits idx0[0..m) from the cache alone: record from (g, G) -> the B scalar updates -> g update, block by
+// block; nothing n-sized is touched.  r learns about the moves later (sync_r).
+template <int NG> int32_t launch_cov_chunk(cdh_handle h, int m) {
+    using R = GramRec<NG>;
+    constexpr int B = R::B;
+    GradCache& c = h->gc;
+    for (int pos0 = 0; pos0 < m; pos0 += B) {
+        const int nb = std::min(B, m - pos0);
+        hipLaunchKernelGGL((k_cov_record<NG>), dim3(1), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot, h->p, h->d_idx, pos0, nb, h->d_red);
+        hipLaunchKernelGGL((k_gram_scalar<NG>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb, h->chunk_dup ? 1 : 0, h->d_ctrl,
+                           h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos0);
+        hipLaunchKernelGGL(k_cov_gupdate, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot, h->p,
+                           h->d_idx, h->d_hs, pos0, nb);
+    }
+    return CDH_OK;
+}
+
+// enqueue the visits, bring the results and the updated g back into staging (h_hs / h_newval / h_touched /
+// h_ctrl, c.g_new) -- nothing on the host has changed yet
+int32_t cov_run(cdh_handle h, const int64_t* idx0, int m) {
+    GradCache& c = h->gc;
+    std::memcpy(h->h_idx, idx0, sizeof(int64_t) * (size_t)m);
+    note_duplicates(h, idx0, m);
+    HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(c.d_g, c.g.data(), sizeof(double) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
+    h->ctrl.maxH = 0.0;
+    h->ctrl.domain_error = 0;
+    CHK(upload_ctrl(h));
+    // the width of the handle's blocked sweep where it has one (same recurrence, same kernel), else 16
+    const int B = (h->mode == CDH_SWEEP_BLOCK && h->blockB >= 16) ? h->blockB : 16;
+    if (B == 64) CHK(launch_cov_chunk<4>(h, m));
+    else if (B == 32) CHK(launch_cov_chunk<2>(h, m));
+    else CHK(launch_cov_chunk<1>(h, m));
+    HIPCHK(h, hipGetLastError());
+    c.g_new.resize((size_t)h->p);
+    HIPCHK(h, hipMemcpyAsync(c.g_new.data(), c.d_g, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_hs, h->d_hs, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_newval, h->d_newval, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_touched, h->d_touched, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+// the staged results of visit i become real: SparseIterate writes, the move noted for r, maxH
+void cov_apply_visit(cdh_handle h, int64_t k, int i) {
+    if (h->h_touched[i] && h->x.get(k) == 0.0) h->x.set(k, 1.0);  // pre-prox non-zero: slot appended
+    h->x.set(k, h->h_newval[i]);
+    const double hv = h->h_hs[i];
+    if (hv == 0.0) return;
+    if (!h->r_in_pending[(size_t)k]) { h->r_in_pending[(size_t)k] = 1; h->r_pending_list.push_back(k); }
+    h->r_pending[(size_t)k] += hv;
+    if (hv == hv && h->gc.beta_ok) h->gc.beta_ref[(size_t)k] += hv;
+}
+void cov_accept_tail(cdh_handle h, int m, double* maxH) {
+    GradCache& c = h->gc;
+    const double mh = h->h_ctrl->maxH;
+    if (mh > *maxH) *maxH = mh;
+    c.g.swap(c.g_new);
+    c.n_cov += m;
+    c.cov_since_ref += m;
+    bool nan = false;
+    for (int i = 0; i < m; ++i) nan = nan || (h->h_hs[i] != h->h_hs[i]);
+    if (nan) gc_invalidate(h, false);   // r turns NaN at the catch-up, as in the reference; the cache knows nothing any more
+}
+// a chunk in which every position is visited (the active passes of a solve)
+int32_t cov_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
+    CHK(cov_run(h, idx0, m));
+    for (int i = 0; i < m; ++i) cov_apply_visit(h, idx0[i], i);
+    cov_accept_tail(h, m, maxH);
+    return CDH_OK;
+}
+// the visits never happened: beta on the device goes back to what the host-side iterate still says
+int32_t cov_reject(cdh_handle h, const int64_t* idx0, int m) {
+    for (int i = 0; i < m; ++i) { h->h_idx[i] = idx0[i]; h->h_hs[i] = h->x.get(idx0[i]); }
+    HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_hs, h->h_hs, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_scatter_f64, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, h->beta, h->d_idx, h->d_hs, m);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+
 // g = X'r and a = diag(X'X) from one dots-only pass over all of X: the new reference point
 int32_t gc_validate(cdh_handle h) {
     GradCache& c = h->gc;
@@ -41,6 +178,7 @@ int32_t gc_validate(cdh_handle h) {
     c.moved.clear();
     c.valid = true;
     c.n_validate += 1;
+    c.cov_since_ref = 0;
     return CDH_OK;
 }
 
@@ -88,6 +226,7 @@ int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
             c.slot[(size_t)todo[b0 + (size_t)b]] = (int32_t)(c.G.size() - 1);
         }
         c.n_batches += 1; c.n_columns += nbc;
+        CHK(gc_dev_upload(h));
     }
     return CDH_OK;
 }
@@ -131,6 +270,9 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     const std::vector<double>& om = h->h_omega;
     // 1. a current g: fold the pending moves, fetching the columns that are missing; too many missing (or no
     //    reference yet): one dots-only pass over X gives a fresh g instead
+    // g has been carried through this many covariance-form updates without looking at X: take it afresh
+    // (rounding only ever accumulates in g; one dots-only pass resets it)
+    if (c.valid && c.cov_since_ref > kGcCovRefresh) gc_invalidate(h, false);
     std::vector<int64_t> want;
     if (c.valid) {
         for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) want.push_back(j);
@@ -226,11 +368,70 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
             ++pos;
             continue;
         }
-        // exact visits [pos, end): up to the last unsettled position that is no more than 4 past the previous one
+        // Covariance form (least squares, every unsettled coordinate ahead has its Gram column): the unsettled
+        // positions of a window go down as ONE chunk and the settled positions between them are skipped; since
+        // a settled coordinate's certificate was read BEFORE the chunk's moves, it is re-checked afterwards
+        // against the gradient as it stood when its turn came (the movers' columns are at hand).  A certificate
+        // that no longer holds -- rare -- rolls the chunk back and reruns it up to that position.
+        if (c.cov && h->loss == CDH_LS && c.moved.empty() && c.d_G && c.dev_slots == (int64_t)c.G.size()) {
+            std::vector<int64_t> upos;
+            int64_t wend = pos;
+            bool have_all = true;
+            for (; wend < m && (int64_t)upos.size() < maxlen && wend - pos < kGcCovWindow; ++wend)
+                if (!settled(idx0[wend])) {
+                    if (c.slot[(size_t)idx0[wend]] < 0) { have_all = false; break; }
+                    upos.push_back(wend);
+                }
+            if (have_all || !upos.empty()) {
+                if (!have_all) wend = upos.back() + 1;        // stop the window before the column-less coordinate
+                for (;;) {
+                    std::vector<int64_t> vis(upos.size());
+                    for (size_t i = 0; i < upos.size(); ++i) vis[i] = idx0[upos[i]];
+                    const int mv = (int)vis.size();
+                    CHK(cov_run(h, vis.data(), mv));
+                    // re-check the skipped positions in visit order, carrying g through the chunk's moves
+                    std::vector<double> gv(c.g);
+                    int64_t bad = -1;
+                    size_t iu = 0;
+                    auto settled_at = [&](int64_t kq) {
+                        return h->x.get(kq) == 0.0 && c.a[(size_t)kq] > 0.0 && std::fabs(gv[(size_t)kq]) <= thr_of(kq);
+                    };
+                    for (int64_t q = pos; q < wend; ++q) {
+                        if (iu < upos.size() && upos[iu] == q) {
+                            const double hv = h->h_hs[iu];
+                            if (hv != 0.0) {
+                                const std::vector<double>& col = c.G[(size_t)c.slot[(size_t)vis[iu]]];
+                                for (int64_t kk = 0; kk < h->p; ++kk) gv[(size_t)kk] -= hv * col[(size_t)kk];
+                            }
+                            ++iu;
+                        } else if (!settled_at(idx0[q])) { bad = q; break; }
+                    }
+                    if (bad < 0) {
+                        iu = 0;
+                        for (int64_t q = pos; q < wend; ++q) {      // bookkeeping in visit order
+                            const int64_t kq = idx0[q];
+                            if (iu < upos.size() && upos[iu] == q) { cov_apply_visit(h, kq, (int)iu); ++iu; c.n_exact += 1; }
+                            else { if (c.g[(size_t)kq] != 0.0) h->x.set(kq, 1.0); h->x.set(kq, 0.0); c.n_certified += 1; }
+                        }
+                        cov_accept_tail(h, mv, maxH);
+                        break;
+                    }
+                    CHK(cov_reject(h, vis.data(), mv));
+                    c.n_rollbacks += 1;
+                    wend = bad;                                      // position `bad` starts the next window
+                    while (!upos.empty() && upos.back() >= bad) upos.pop_back();
+                }
+                pos = wend;
+                if (!c.valid) { *handled = true; break; }
+                continue;
+            }
+        }
+        // streamed visits [pos, end): up to the last unsettled position that is no more than 4 past the previous one
         int64_t end = pos + 1;
         for (int64_t q = pos + 1; q < m && q - end < 4 && end - pos < maxlen; ++q)
             if (!settled(idx0[q])) end = q + 1;
-        CHK(run_chunk(h, idx0 + pos, (int)(end - pos), maxH));
+        if (cov_ok(h, idx0 + pos, end - pos)) CHK(cov_chunk(h, idx0 + pos, (int)(end - pos), maxH));
+        else CHK(run_chunk(h, idx0 + pos, (int)(end - pos), maxH));
         c.n_exact += end - pos;
         pos = end;
         if (!c.valid) { *handled = true; break; }     // a NaN step: finish below the plain way

@@ -624,6 +624,56 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_cross(const T* __restric
     }
 }
 
+// ---- covariance-form visits (cdhip.hip / grad_cache.hpp, "cov chunks") --------------------------------------
+// While the gradient cache holds g = X'r and the Gram columns G_j = X'X_j of every coordinate of a chunk,
+// the block record k_gram_scalar consumes -- c_i = X_ki'r, G_si = X_ks'X_ki, a_i = G_ii -- can be read off
+// the cache instead of being streamed from X: no HBM traffic for the visit at all.  k_cov_record gathers the
+// record of visits [pos0, pos0 + nb); k_gram_scalar runs the same B sequential updates as in the streamed
+// sweep; k_cov_gupdate then applies g -= sum_i h_i G_ki to all p entries.  The residual is brought up to
+// date later, once (k_multi_axpy over the coordinates that moved).  Least squares, fp64.
+template <int NG>
+__global__ __launch_bounds__(256) void k_cov_record(const double* __restrict__ g, const double* __restrict__ Gcols,
+                                                    const int32_t* __restrict__ slot, int64_t p,
+                                                    const int64_t* __restrict__ idx, int pos0, int nb,
+                                                    double* __restrict__ rec) {
+    using R = GramRec<NG>;
+    constexpr int B = R::B;
+    __shared__ int64_t s_k[B];
+    __shared__ int64_t s_off[B];
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const int64_t k = idx[pos0 + (i < nb ? i : 0)];
+        s_k[i] = k;
+        s_off[i] = (int64_t)slot[k] * p;
+    }
+    __syncthreads();
+    // G[s][j] for s <= j < nb (what k_gram_scalar reads: column j above the diagonal, and the diagonal)
+    for (int e = threadIdx.x; e < B * B; e += blockDim.x) {
+        const int sI = e / B, j = e % B;
+        if (sI <= j && j < nb) rec[R::g(sI, j)] = Gcols[s_off[j] + s_k[sI]];
+    }
+    for (int i = threadIdx.x; i < B; i += blockDim.x) rec[R::OFF_C + i] = (i < nb) ? g[s_k[i]] : 0.0;
+    if (threadIdx.x == 0) rec[R::OFF_Q] = 0.0;   // r'r: only the sqrt-lasso update reads it, and that one is streamed
+}
+
+__global__ void k_scatter_f64(double* __restrict__ dst, const int64_t* __restrict__ idx, const double* __restrict__ val, int m) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) dst[idx[i]] = val[i];
+}
+
+__global__ __launch_bounds__(256) void k_cov_gupdate(double* __restrict__ g, const double* __restrict__ Gcols,
+                                                     const int32_t* __restrict__ slot, int64_t p,
+                                                     const int64_t* __restrict__ idx,
+                                                     const double* __restrict__ hs, int pos0, int nb) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p) return;
+    double acc = g[k];
+    for (int i = 0; i < nb; ++i) {            // uniform over the block: scalar loads, skipped when the visit did not move
+        const double h = hs[pos0 + i];
+        if (h != 0.0) acc = fma(-h, Gcols[(int64_t)slot[idx[pos0 + i]] * p + k], acc);
+    }
+    g[k] = acc;
+}
+
 // r -= sum_i hs[pos0+i] X[:, idx[pos0+i]], i < nprev: the trailing update of a pass (any width)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_multi_axpy(const T* __restrict__ X, int64_t ld,

@@ -205,11 +205,16 @@ int32_t cdh_set_screening(cdh_handle h, int32_t on);
  * Modes 1 and 2 engage only while n_total >= 400 * nnz(x): folding a move into the cached gradient is p host
  * flops, which beats re-reading X only on tall problems; mode 3 is mode 2 without that guard (tests).
  * Same iterates, support order and pass counts as visiting every coordinate.
- * cdh_cache_stats: out6 = {passes served, visits settled from the cache, visits made, dots-only
- * re-reference passes over X, Gram batches (up to 32 columns, at most 1.5 passes over X each), Gram
- * columns held}. */
+ * While the cache is engaged the visits themselves need no read of X either (least squares): the block
+ * record the scalar-update kernel consumes -- X_k'r, the Gram entries between the block's coordinates -- is
+ * read off the cached gradient and Gram columns ("covariance form"), and r is brought up to date once, before
+ * anything reads it and before any entry point returns.
+ * cdh_cache_stats: out9 = {passes served, visits settled from the cache, visits made in those passes,
+ * dots-only re-reference passes over X, Gram batches (up to 32 columns, at most 1.5 passes over X each),
+ * Gram columns held, visits made in covariance form, residual catch-ups, covariance chunks rolled back
+ * because a skipped coordinate's certificate did not survive the chunk's own moves}. */
 int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode);
-int32_t cdh_cache_stats(cdh_handle h, int64_t *out6);
+int32_t cdh_cache_stats(cdh_handle h, int64_t *out9);
 /* Replay each pass from a captured hipGraph instead of individual launches (the north_star's
  * "full sweep captured under hipGraph").  Works on row shards too: the direct exchange takes its epoch
  * from device memory, RCCL all-reduces are captured with the kernels around them; only the host-staged
