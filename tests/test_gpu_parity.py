@@ -1017,3 +1017,45 @@ def test_gradient_cache_default_mode_engages_on_tall_problems_only():
         cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
     assert x.nnz > 1 and f.cache_stats()["passes"] == 0 and f.cache_stats()["gram_columns"] == 0
     f.close()
+
+
+def test_covariance_chunks_roll_back_when_a_skipped_certificate_breaks():
+    """Inside one covariance-form chunk the settled positions between two visits are skipped on the strength of
+    certificates read BEFORE the chunk's moves.  On a design whose neighbouring columns are 0.97-correlated, a
+    move flips its neighbour's certificate within the same chunk: the library must notice (it re-checks every
+    skipped position against the gradient as it stood at its turn), roll the chunk back and rerun it shorter.
+    Pass by pass against the oracle, from iterates away from the optimum; at least one rollback must have
+    happened, or this test exercises nothing."""
+    rollbacks = 0
+    for seed in range(6):
+        rng = np.random.default_rng(900 + seed)
+        n, p = 1500, 260
+        z = rng.standard_normal((n, p))
+        X = z.copy()
+        for j in range(1, p):                      # a chain: column j is 0.97-correlated with column j - 1
+            X[:, j] = 0.97 * X[:, j - 1] + np.sqrt(1 - 0.97 ** 2) * z[:, j]
+        X = np.asfortranarray(X)
+        Y = X[:, [20, 90, 91, 180]] @ np.array([2.0, -1.5, 1.0, 0.8]) + 0.5 * rng.standard_normal(n)
+        lam = 0.25
+        f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+        f.set_sweep_mode("block", 16)
+        f.set_gradient_cache(3)
+        f.set_screening(2)
+        g, go = cd.ProxL1(lam), O.ProxL1(lam)
+        x0 = np.zeros(p)
+        x0[[20, 90, 180]] = [3.5, -3.0, 2.5]       # far from the optimum: the first passes move a lot
+        x, xo = cd.SparseIterate(p, x0), O.SparseIterate(p, x0)
+        cd.initialize_(f, x)
+        O.initialize_(fo, xo)
+        visit = list(range(1, p + 1))
+        for _ in range(12):
+            mh, mho = cd.cdPass_(x, f, g, visit), O.cdPass_(xo, fo, go, visit)
+            np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-10)
+            np.testing.assert_allclose(mh, mho, rtol=1e-8, atol=1e-13)
+            assert x.nzval2ind.tolist() == xo.nzval2ind.tolist()
+        np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-9)
+        cs = f.cache_stats()
+        assert cs["covariance_visits"] > 0
+        rollbacks += cs["rollbacks"]
+        f.close()
+    assert rollbacks > 0
