@@ -999,6 +999,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
                                                 (size_t)cus * kBlockGridPerCU * BlockRec<kMaxBlockB>::N,
                                                 (size_t)4096 * kColChunks * 2,
                                                 (size_t)cus * 2 * GramRec<4>::N,
+                                                (size_t)cus * 2 * kCrossRec,
                                                 (size_t)cus * std::max(h->gram32_per_cu, 4) * GramRec<2>::N,
                                                 (size_t)cus * 4 * GramRec<1>::N});
         HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * h->partials_doubles));

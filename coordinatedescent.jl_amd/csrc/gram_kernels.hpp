@@ -543,12 +543,27 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
 // G_j = X'X_j for every moved j, X_k'r is known for every k without reading X again.  Same use of the
 // matrix pipe as k_gramstep -- a 16 x 16 fp64 accumulator tile in 8 registers, rows of X as the K
 // dimension, lane (c, g) loading 16 bytes of column c at vector 4u + g -- with separate A and B operands
-// (4 x 2 tiles).  HBM-bound: (64 + nb) columns read for 64 x nb products -- B columns that are not
-// asked for are not loaded -- i.e. 1.5 passes over X per 32 Gram columns.  fp32 storage is widened to
+// (4 x 2 tiles).  (64 + nb) columns read for 64 x nb products -- B columns that are not asked for are not
+// loaded -- i.e. 1.5 passes over X per 32 Gram columns.  Measured on cfg3 (n = 2e6: 237 launches x 355 us =
+// 84 ms for 96 columns, 4.3 TB/s, matrix pipe ~1/3 busy): neither HBM nor the pipe is saturated, and the
+// total does not move with 6 or 8 A tiles per launch, 1 / 2 / 4 vector rows of loads in flight or 3 waves
+// per SIMD (tools/cross_scan.sh: 82 .. 90 ms) -- what is left is the load -> MFMA dependency of a wave
+// with one group of loads in flight, on launches only ~8 chunks per wave long.  fp32 storage is widened to
 // fp64 on the way in (an occasional pass, not the sweep).
-constexpr int kCrossA = 64, kCrossB = 32, kCrossTA = 4, kCrossTB = 2, kCrossRec = kCrossTA * kCrossTB * 256;
+#ifndef CDH_CROSS_TA
+#define CDH_CROSS_TA 4
+#endif
+#ifndef CDH_CROSS_UH
+#define CDH_CROSS_UH 2
+#endif
+#ifndef CDH_CROSS_OCC
+#define CDH_CROSS_OCC 2
+#endif
+constexpr int kCrossTA = CDH_CROSS_TA, kCrossTB = 2, kCrossA = 16 * kCrossTA, kCrossB = 16 * kCrossTB,
+              kCrossRec = kCrossTA * kCrossTB * 256;
+constexpr int kCrossUH = CDH_CROSS_UH;   // vector rows of fragment loads in flight per group
 template <typename T>
-__global__ __launch_bounds__(64 * kGramWaves, 2) void k_cross(const T* __restrict__ X, int64_t ld, int64_t nvec,
+__global__ __launch_bounds__(64 * kGramWaves, CDH_CROSS_OCC) void k_cross(const T* __restrict__ X, int64_t ld, int64_t nvec,
                                                               const int64_t* __restrict__ acols, int na,
                                                               const int64_t* __restrict__ bcols, int nbc,
                                                               double* __restrict__ partials) {
@@ -578,10 +593,10 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_cross(const T* __restric
     for (int64_t ch = (int64_t)wave * gridDim.x + blockIdx.x; ch < nchunks; ch += (int64_t)gridDim.x * kGramWaves) {
         const int64_t v0 = ch * 64;
 #pragma unroll 1
-        for (int u0 = 0; u0 < 16; u0 += 4) {
-            V xa[4][kCrossTA], xb[4][kCrossTB];
+        for (int u0 = 0; u0 < 16; u0 += kCrossUH) {
+            V xa[kCrossUH][kCrossTA], xb[kCrossUH][kCrossTB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kCrossUH; ++u) {
                 const int64_t v = v0 + 4 * (u0 + u) + g;
                 const bool in = v < nvec;
 #pragma unroll
@@ -592,7 +607,7 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void k_cross(const T* __restric
                     xa[u][grp] = (aact[grp] && in) ? ld_stream<true>(av[grp] + v) : vzero((V*)nullptr);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < kCrossUH; ++u)
 #pragma unroll
                 for (int e = 0; e < NV; ++e) {
                     double b[kCrossTB];
@@ -664,13 +679,30 @@ __global__ __launch_bounds__(256) void k_cov_gupdate(double* __restrict__ g, con
                                                      const int32_t* __restrict__ slot, int64_t p,
                                                      const int64_t* __restrict__ idx,
                                                      const double* __restrict__ hs, int pos0, int nb) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= p) return;
-    double acc = g[k];
-    for (int i = 0; i < nb; ++i) {            // uniform over the block: scalar loads, skipped when the visit did not move
-        const double h = hs[pos0 + i];
-        if (h != 0.0) acc = fma(-h, Gcols[(int64_t)slot[idx[pos0 + i]] * p + k], acc);
+    // the block's moves first, fetched side by side (idx -> slot -> column is a dependent chain per visit:
+    // walked serially it cost 8 us for 32 visits), compacted to those with h != 0
+    __shared__ double s_h[64];
+    __shared__ int64_t s_off[64];
+    __shared__ int s_n;
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        double h = 0.0;
+        int64_t off = 0;
+        if (i < nb) { h = hs[pos0 + i]; off = (int64_t)slot[idx[pos0 + i]] * p; }
+        const bool nz = (h != 0.0);
+        const unsigned long long mask = __ballot(nz);
+        if (nz) {
+            const int at = __popcll(mask & ((1ull << i) - 1ull));
+            s_h[at] = h; s_off[at] = off;
+        }
+        if (i == 0) s_n = __popcll(mask);
     }
+    __syncthreads();
+    const int nmove = s_n;
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p || nmove == 0) return;
+    double acc = g[k];
+    for (int i = 0; i < nmove; ++i) acc = fma(-s_h[i], Gcols[s_off[i] + k], acc);
     g[k] = acc;
 }
 
