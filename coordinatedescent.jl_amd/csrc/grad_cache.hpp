@@ -23,8 +23,13 @@ int32_t gc_size(cdh_handle h) {   // first use on this handle
     if (c.beta_ok)
         for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) c.beta_ref[(size_t)h->x.coord(s_)] = h->x.slot_value(s_);
     const int64_t launches = (h->p + kCrossA - 1) / kCrossA;
-    HIPCHK(h, hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec));
-    HIPCHK(h, hipMalloc((void**)&c.d_cols, sizeof(int64_t) * (p + kCrossA + kCrossB)));
+    if (hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec) != hipSuccess ||
+        hipMalloc((void**)&c.d_cols, sizeof(int64_t) * (p + kCrossA + kCrossB)) != hipSuccess) {
+        (void)hipGetLastError();      // no room for the cache's scratch: the handle keeps the dots-only screens
+        c.mode = 0;
+        c.g.clear(); c.g.shrink_to_fit();
+        return CDH_OK;
+    }
     std::vector<int64_t> ident(p + kCrossA + kCrossB, 0);
     for (size_t k = 0; k < p; ++k) ident[k] = (int64_t)k;
     HIPCHK(h, hipMemcpy(c.d_cols, ident.data(), sizeof(int64_t) * ident.size(), hipMemcpyHostToDevice));
@@ -39,15 +44,17 @@ int32_t gc_dev_upload(cdh_handle h) {
     GradCache& c = h->gc;
     if (!c.cov) return CDH_OK;
     const int64_t p = h->p, have = (int64_t)c.G.size();
+    // no room on the device for the mirrors is not an error: the visits simply stay in residual form
+    auto no_room = [&]() { (void)hipGetLastError(); c.cov = false; return (int32_t)CDH_OK; };
     if (!c.d_g) {
-        HIPCHK(h, hipMalloc((void**)&c.d_g, sizeof(double) * (size_t)p));
-        HIPCHK(h, hipMalloc((void**)&c.d_slot, sizeof(int32_t) * (size_t)p));
+        if (hipMalloc((void**)&c.d_g, sizeof(double) * (size_t)p) != hipSuccess) return no_room();
+        if (hipMalloc((void**)&c.d_slot, sizeof(int32_t) * (size_t)p) != hipSuccess) return no_room();
     }
     if (have > c.dev_slots_cap) {   // grow the store (64 columns at a time, at most kGcMaxBytes), keeping what is there
         const int64_t cap = std::min<int64_t>((have + 63) / 64 * 64 + 64, (int64_t)(kGcMaxBytes / sizeof(double)) / std::max<int64_t>(p, 1));
         if (cap < have) { c.cov = false; return CDH_OK; }   // does not fit: the visits stay in residual form
         double* bigger = nullptr;
-        HIPCHK(h, hipMalloc((void**)&bigger, sizeof(double) * (size_t)cap * (size_t)p));
+        if (hipMalloc((void**)&bigger, sizeof(double) * (size_t)cap * (size_t)p) != hipSuccess) return no_room();
         if (c.d_G && c.dev_slots > 0)
             HIPCHK(h, hipMemcpyAsync(bigger, c.d_G, sizeof(double) * (size_t)c.dev_slots * (size_t)p, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
