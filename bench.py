@@ -11,12 +11,15 @@ SURVEY's 1e-3 * lambda_max would leave 90% of the coordinates at zero.)
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME 10M x 1000
 problem with rows sharded across ranks (strong scaling), gradient scalars summed by an
-RCCL all-reduce inside the library (--exchange rccl, the default: the only exchange in the
-timed region, nothing else runs afterwards).  --exchange auto additionally times the same K
-steps over the opt-in direct exchange AFTER the RCCL result line has been printed and flushed,
-and prints a second line with the faster validated one (adopt_direct_exchange).
+RCCL all-reduce inside the library: that region is always timed first.  With --exchange auto
+(the default) the direct exchange is then PROBED IN PROCESSES OF ITS OWN on the same GPUs
+(coordinatedescent.jl_amd/p2p_probe.py: whatever a transport that has never run on this
+hardware can do, it does there); only if every rank's probe validated are the same K steps timed
+over it in this process, and `value` is the faster of the two if the direct one validated again
+(adopt_direct_exchange) -- the other timing is in `exchange_trial`.  --exchange rccl:
+RCCL only, nothing afterwards.
 
-Prints ONE JSON line on rank 0 (two with --exchange auto at N > 1: the RCCL line first).  `roofline` is computed from HIP events recorded on the
+Prints ONE JSON line on rank 0.  `roofline` is computed from HIP events recorded on the
 library's own stream around the sweep kernels; `cpu_baseline` times the CPU oracle's
 restatement of the reference visit (kind "port": the reference is Julia, not runnable
 here) on a bounded sample of the same data.
@@ -180,6 +183,44 @@ def cfg3_path(device=0, n=2_000_000, p=5000, nlam=100):
         f.close()
 
 
+def isolated_p2p_probe(cp, device, timeout_s=90):
+    """One child process per rank (same GPU, fresh rendezvous port) runs coordinatedescent.jl_amd/p2p_probe.py.
+    Returns (ok on every rank, info).  Nothing the children do can hurt this process: they are waited for with
+    a timeout and killed by PID if they overstay."""
+    import socket
+    import struct
+    import subprocess
+    port = 0
+    if cp.rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    port = struct.unpack("<q", cp.broadcast_bytes(struct.pack("<q", port), 8, src=0))[0]
+    env = dict(os.environ, RANK=str(cp.rank), LOCAL_RANK=str(cp.local_rank), WORLD_SIZE=str(cp.world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # the children rendezvous among themselves: nothing of the launcher's agent may leak in (with
+    # TORCHELASTIC_USE_AGENT_STORE set, rank 0 would wait for a store nobody serves on the new port)
+    for k in [k for k in env if k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+                                                                      "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "LOCAL_WORLD_SIZE")]:
+        env.pop(k, None)
+    script = os.path.join(ROOT, "coordinatedescent.jl_amd", "p2p_probe.py")
+    ok, info = False, {}
+    try:
+        r = subprocess.run([sys.executable, script, str(device)], env=env, capture_output=True, text=True,
+                           timeout=timeout_s, cwd=ROOT)
+        line = [l for l in r.stdout.splitlines() if l.startswith("P2P_PROBE_")]
+        ok = r.returncode == 0 and bool(line) and line[-1].startswith("P2P_PROBE_OK")
+        info = {"rc": r.returncode, "line": line[-1] if line else None}
+        if ok:
+            info["latency_us"] = float(line[-1].split()[1])
+    except subprocess.TimeoutExpired:
+        info = {"rc": None, "line": "timeout"}
+    except Exception as e:             # pragma: no cover
+        info = {"rc": None, "line": str(e)[:120]}
+    all_ok = cp.sum_over_ranks(1.0 if ok else 0.0) == cp.world
+    return all_ok, info
+
+
 def adopt_direct_exchange(mode, selftest_ok, all_ranks_completed, max_abs_dbeta, t_direct, t_rccl):
     """--exchange auto: the direct exchange's timing becomes `value` only if it validated in this very
     run (self-test on every rank, every rank completed the K steps, beta within 1e-9 of the RCCL
@@ -206,10 +247,10 @@ def main():
     ap.add_argument("--lam-frac", type=float, default=1e-6, help="lambda / lambda_max")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the secondary sparse-regime timing")
-    ap.add_argument("--exchange", default=os.environ.get("CDH_EXCHANGE", "rccl"), choices=["auto", "rccl", "p2p"],
-                    help="exchange when sharded.  rccl (default) / p2p: that exchange only, one result line.  "
-                         "auto: time K steps over RCCL, print that line, then K steps over the direct exchange "
-                         "if it validates and print a second line with the faster (the other in exchange_trial)")
+    ap.add_argument("--exchange", default=os.environ.get("CDH_EXCHANGE", "auto"), choices=["auto", "rccl", "p2p"],
+                    help="exchange when sharded.  auto (default): time K steps over RCCL; probe the direct exchange "
+                         "in separate processes; if every rank's probe validated, time K steps over it here and "
+                         "report the faster validated one (the other in exchange_trial).  rccl / p2p: that exchange only")
     ap.add_argument("--no-rccl", action="store_true",
                     help="TEST ONLY (ranks sharing one GPU, which RCCL refuses): build no communicator; with "
                          "--exchange rccl the timed region then has NO exchange and its numbers mean nothing")
@@ -375,18 +416,17 @@ def main():
     if exch_us:
         res["exchange_latency_us"] = dict(exch_us, doubles=rec_doubles, how="200 back-to-back all-reduces, HIP events")
 
-    # --exchange auto at N > 1: the RCCL result is on stdout (flushed) BEFORE the direct exchange -- which
-    # has never run across GPUs in this pipeline -- is touched; whatever the trial does, that line stands.
+    # --exchange auto at N > 1.  The direct exchange has never run across GPUs in this pipeline, so its first
+    # contact with this machine happens in child processes (isolated_p2p_probe); this process only touches it
+    # after every rank's probe came back clean, and otherwise reports the RCCL region as it is.
     run_trial = cp.world > 1 and a.exchange == "auto" and exchange != "p2p" and not a.no_exchange_trial
-    if run_trial and cp.rank == 0:
-        print(json.dumps(res), flush=True)
-    if run_trial and os.environ.get("CDH_BENCH_TRIAL_ABORT"):
-        # TEST ONLY: the worst a trial can do is take the process down (a GPU fault aborts it); the test
-        # checks that the line above has already reached stdout when that happens
-        cp.barrier()
-        os._exit(3)
     if run_trial:
-        trial, t_loc, ok_loc, err_loc, prof, maxh_p2p = {"exchange": "p2p"}, 0.0, False, 1e300, None, maxh
+        probe_ok, probe_info = isolated_p2p_probe(cp, device)
+        if not probe_ok:
+            res["exchange_trial"] = {"exchange": "p2p", "probe": probe_info, "skipped": "the isolated probe did not validate on every rank"}
+            run_trial = False
+    if run_trial:
+        trial, t_loc, ok_loc, err_loc, prof, maxh_p2p = {"exchange": "p2p", "probe": probe_info}, 0.0, False, 1e300, None, maxh
         try:
             connected = sharded.connect_p2p(f, cp)
         except Exception as e:          # pragma: no cover - connect_p2p is written not to raise
@@ -438,7 +478,7 @@ def main():
                 if k in rccl_line:
                     res[k] = rccl_line[k]
             trial = {"exchange": "rccl", "ms_per_step": dt / a.steps * 1e3, "p2p_selftest": True,
-                     "max_abs_dbeta_p2p_vs_rccl": err_max}
+                     "max_abs_dbeta_p2p_vs_rccl": err_max, "probe": probe_info}
         res["exchange_trial"] = trial
         if exch_us:
             res["exchange_latency_us"] = dict(exch_us, doubles=rec_doubles, how="200 back-to-back all-reduces, HIP events")

@@ -498,7 +498,7 @@ def test_sharded_launch_sequence_over_host_exchange(ranks):
     assert "HOSTX_OK" in a.stdout
 
 
-def _bench_two_ranks_one_gpu(extra, lines=1, env_extra=None, rc=0):
+def _bench_two_ranks_one_gpu(extra, env_extra=None):
     import json
     import subprocess
     import sys
@@ -511,28 +511,26 @@ def _bench_two_ranks_one_gpu(extra, lines=1, env_extra=None, rc=0):
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(root, "bench.py"), "--gpus", "2", "--no-rccl"] + cmd + extra,
                        capture_output=True, text=True, timeout=420, env=env, cwd=root)
-    assert (a.returncode == 0) == (rc == 0), (a.stdout[-1500:], a.stderr[-3000:])
+    assert a.returncode == 0, (a.stdout[-1500:], a.stderr[-3000:])
     got = [l for l in a.stdout.splitlines() if l.startswith("{")]
-    assert len(got) == lines, got          # one result line; with --exchange auto the RCCL-region line comes first
-    if rc != 0:
-        return json.loads(got[0]), None
+    assert len(got) == 1, got            # the contract: ONE result line, whatever the exchange mode
     b = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + cmd,
                        capture_output=True, text=True, timeout=420, cwd=root)
     assert b.returncode == 0, b.stderr[-2000:]
     last = lambda out: json.loads([l for l in out.splitlines() if l.startswith("{")][-1])  # noqa: E731
-    if lines == 2:    # the first line is the complete result of the first timed region, printed before the trial
-        first = json.loads(got[0])
-        assert first["metric"] == "coord_updates_per_sec" and first["value"] > 0 and "exchange_trial" not in first
     return last(a.stdout), last(b.stdout)
 
 
-def test_bench_first_line_survives_a_trial_that_kills_the_process():
-    """--exchange auto: the result of the first timed region is on stdout before the direct-exchange
-    trial starts, so a trial that takes the ranks down (here: os._exit in every rank, the stand-in for
-    a GPU fault) cannot lose it."""
-    first, _ = _bench_two_ranks_one_gpu(["--exchange", "auto"], lines=1, env_extra={"CDH_BENCH_TRIAL_ABORT": "1"}, rc=3)
-    assert first["n_gpus"] == 2 and first["value"] > 0 and first["ms_per_step"] > 0
-    assert first["ms_per_step_ranks"]["min"] <= first["ms_per_step_ranks"]["max"] <= first["ms_per_step"] * 1.001
+def test_bench_a_direct_exchange_probe_that_dies_costs_nothing():
+    """--exchange auto (the default): the direct exchange meets the machine in child processes first.  Here every
+    probe dies on the spot (os._exit, the stand-in for a GPU fault in a transport that has never run on this
+    hardware): the bench process never touches the direct exchange, exits 0 and prints the first timed region."""
+    ja, _ = _bench_two_ranks_one_gpu(["--exchange", "auto"], env_extra={"CDH_P2P_PROBE_ABORT": "1"})
+    assert ja["n_gpus"] == 2 and ja["value"] > 0 and ja["ms_per_step"] > 0
+    t = ja["exchange_trial"]
+    assert "skipped" in t and t["probe"]["rc"] == 3 and "ms_per_step" not in t
+    assert ja["exchange_stats"]["p2p_calls"] == 0
+    assert ja["ms_per_step_ranks"]["min"] <= ja["ms_per_step_ranks"]["max"] <= ja["ms_per_step"] * 1.001
 
 
 def test_bench_sharded_with_p2p_exchange_two_ranks_one_gpu():
@@ -546,8 +544,9 @@ def test_bench_sharded_with_p2p_exchange_two_ranks_one_gpu():
 def test_bench_exchange_trial_code_path_two_ranks_one_gpu():
     """The guarded trial bench.py runs after an RCCL-timed region, exercised without RCCL (--no-rccl:
     the timed region has no exchange, so only the trial's own fields are meaningful here)."""
-    ja, _ = _bench_two_ranks_one_gpu(["--exchange", "auto"], lines=2)
+    ja, _ = _bench_two_ranks_one_gpu([])               # --exchange auto is the default
     t = ja["exchange_trial"]
+    assert t["probe"]["rc"] == 0 and t["probe"]["line"].startswith("P2P_PROBE_OK") and t["probe"]["latency_us"] > 0
     assert t["selftest"] is True and t["completed_on_all_ranks"] is True and t["ms_per_step"] > 0
     assert "error" not in t
     assert 0.0 < ja["exchange_latency_us"]["p2p"] < 1e4 and ja["exchange_latency_us"]["doubles"] == 273
