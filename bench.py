@@ -183,7 +183,7 @@ def cfg3_path(device=0, n=2_000_000, p=5000, nlam=100):
         f.close()
 
 
-def isolated_p2p_probe(cp, device, timeout_s=90):
+def isolated_p2p_probe(cp, device, timeout_s=150):
     """One child process per rank (same GPU, fresh rendezvous port) runs coordinatedescent.jl_amd/p2p_probe.py.
     Returns (ok on every rank, info).  Nothing the children do can hurt this process: they are waited for with
     a timeout and killed by PID if they overstay."""
