@@ -98,7 +98,7 @@ struct GradCache {
     std::vector<double> h_cross;
     // covariance-form visits: device mirrors of g, the Gram columns (slot-major, p doubles each) and the slot map
     bool cov = true;                // env CDH_GC_COV
-    double *d_g = nullptr, *d_G = nullptr;
+    double *d_g = nullptr, *d_G = nullptr, *h_g_pin = nullptr;
     int32_t* d_slot = nullptr;
     int64_t dev_slots_cap = 0, dev_slots = 0;   // columns the device store can hold / holds
     int64_t cov_since_ref = 0;      // covariance-form visits since g was last taken from X itself
@@ -896,6 +896,7 @@ void free_all(cdh_handle h) {
     if (h->gc.d_g) (void)hipFree(h->gc.d_g);
     if (h->gc.d_G) (void)hipFree(h->gc.d_G);
     if (h->gc.d_slot) (void)hipFree(h->gc.d_slot);
+    if (h->gc.h_g_pin) (void)hipHostFree(h->gc.h_g_pin);
     if (h->h_xchg) (void)hipHostFree(h->h_xchg);
     if (h->p2p_timeout) (void)hipHostFree(h->p2p_timeout);
     for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);

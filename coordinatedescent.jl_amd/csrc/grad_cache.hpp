@@ -49,6 +49,9 @@ int32_t gc_dev_upload(cdh_handle h) {
     if (!c.d_g) {
         if (hipMalloc((void**)&c.d_g, sizeof(double) * (size_t)p) != hipSuccess) return no_room();
         if (hipMalloc((void**)&c.d_slot, sizeof(int32_t) * (size_t)p) != hipSuccess) return no_room();
+        // pinned staging for g on its way down and back (pageable copies are staged by the runtime, one
+        // hidden synchronisation each: two per chunk of visits)
+        if (hipHostMalloc((void**)&c.h_g_pin, sizeof(double) * 2 * (size_t)p) != hipSuccess) return no_room();
     }
     if (have > c.dev_slots_cap) {   // grow the store (64 columns at a time, at most kGcMaxBytes), keeping what is there
         const int64_t cap = std::min<int64_t>((have + 63) / 64 * 64 + 64, (int64_t)(kGcMaxBytes / sizeof(double)) / std::max<int64_t>(p, 1));
@@ -115,7 +118,8 @@ int32_t cov_run(cdh_handle h, const int64_t* idx0, int m) {
     std::memcpy(h->h_idx, idx0, sizeof(int64_t) * (size_t)m);
     note_duplicates(h, idx0, m);
     HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(c.d_g, c.g.data(), sizeof(double) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(c.h_g_pin, c.g.data(), sizeof(double) * (size_t)h->p);
+    HIPCHK(h, hipMemcpyAsync(c.d_g, c.h_g_pin, sizeof(double) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
     h->ctrl.maxH = 0.0;
     h->ctrl.domain_error = 0;
     CHK(upload_ctrl(h));
@@ -126,12 +130,13 @@ int32_t cov_run(cdh_handle h, const int64_t* idx0, int m) {
     else CHK(launch_cov_chunk<1>(h, m));
     HIPCHK(h, hipGetLastError());
     c.g_new.resize((size_t)h->p);
-    HIPCHK(h, hipMemcpyAsync(c.g_new.data(), c.d_g, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(c.h_g_pin + h->p, c.d_g, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_hs, h->d_hs, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_newval, h->d_newval, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_touched, h->d_touched, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(c.g_new.data(), c.h_g_pin + h->p, sizeof(double) * (size_t)h->p);
     return CDH_OK;
 }
 // the staged results of visit i become real: SparseIterate writes, the move noted for r, maxH
