@@ -547,9 +547,11 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
 // loaded -- i.e. 1.5 passes over X per 32 Gram columns.  Measured on cfg3 (n = 2e6: 237 launches x 355 us =
 // 84 ms for 96 columns, 4.3 TB/s, matrix pipe ~1/3 busy): neither HBM nor the pipe is saturated, and the
 // total does not move with 6 or 8 A tiles per launch, 1 / 2 / 4 vector rows of loads in flight or 3 waves
-// per SIMD (tools/cross_scan.sh: 82 .. 90 ms) -- what is left is the load -> MFMA dependency of a wave
-// with one group of loads in flight, on launches only ~8 chunks per wave long.  fp32 storage is widened to
-// fp64 on the way in (an occasional pass, not the sweep).
+// per SIMD, nor with the next group of loads requested before the current group's MFMAs (software
+// pipelining, two groups in flight: 85.5 against 84.8 ms) (tools/cross_scan.sh: 82 .. 92 ms).  The launches
+// are short -- 7.6 chunks per wave at 2e6 rows -- and cost what the fixed + rows / bandwidth model of the
+// Gram kernel predicts to within 15 %.  fp32 storage is widened to fp64 on the way in (an occasional pass,
+// not the sweep).
 #ifndef CDH_CROSS_TA
 #define CDH_CROSS_TA 4
 #endif
