@@ -244,13 +244,40 @@ int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
 }
 
 // g <- g - sum_j dbeta_j G_j over the pending moves (all of which must have their columns)
+// On the device where the column mirrors live (k_cov_gupdate, 64 moves per launch: the arithmetic of the
+// gradient stays on the GPU, the host only compares it with thresholds); on the host only when there are no
+// mirrors (the covariance form switched off, or no room for them).
+bool gc_fold_device(cdh_handle h) {
+    GradCache& c = h->gc;
+    if (!c.cov || !c.d_G || !c.h_g_pin || c.dev_slots != (int64_t)c.G.size()) return false;
+    const int64_t M = (int64_t)c.moved.size();
+    if (M > h->cap) return false;
+    for (int64_t i = 0; i < M; ++i) { h->h_idx[i] = c.moved[(size_t)i]; h->h_hs[i] = c.dbeta[(size_t)c.moved[(size_t)i]]; }
+    std::memcpy(c.h_g_pin, c.g.data(), sizeof(double) * (size_t)h->p);
+    bool ok = hipMemcpyAsync(c.d_g, c.h_g_pin, sizeof(double) * (size_t)h->p, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+              hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)M, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+              hipMemcpyAsync(h->d_hs, h->h_hs, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    for (int64_t pos0 = 0; ok && pos0 < M; pos0 += 64)
+        hipLaunchKernelGGL(k_cov_gupdate, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot,
+                           h->p, h->d_idx, h->d_hs, (int)pos0, (int)std::min<int64_t>(64, M - pos0));
+    ok = ok && hipGetLastError() == hipSuccess &&
+         hipMemcpyAsync(c.h_g_pin + h->p, c.d_g, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+         hipStreamSynchronize(h->stream) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); return false; }
+    std::memcpy(c.g.data(), c.h_g_pin + h->p, sizeof(double) * (size_t)h->p);
+    return true;
+}
+
 void gc_fold(cdh_handle h) {
     GradCache& c = h->gc;
+    if (c.moved.empty()) return;
+    const bool on_device = gc_fold_device(h);
     for (int64_t j : c.moved) {
         const double d = c.dbeta[(size_t)j];
-        const std::vector<double>& col = c.G[(size_t)c.slot[(size_t)j]];
-        if (d != 0.0)
+        if (!on_device && d != 0.0) {
+            const std::vector<double>& col = c.G[(size_t)c.slot[(size_t)j]];
             for (int64_t k = 0; k < h->p; ++k) c.g[(size_t)k] -= d * col[(size_t)k];
+        }
         c.dbeta[(size_t)j] = 0.0; c.in_moved[(size_t)j] = 0;
     }
     c.moved.clear();

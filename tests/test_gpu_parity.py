@@ -1025,6 +1025,8 @@ def test_covariance_chunks_roll_back_when_a_skipped_certificate_breaks():
     skipped position against the gradient as it stood at its turn), roll the chunk back and rerun it shorter.
     Pass by pass against the oracle, from iterates away from the optimum; at least one rollback must have
     happened, or this test exercises nothing."""
+    if os.environ.get("CDH_GC_COV") == "0":
+        pytest.skip("covariance-form visits are switched off by the environment")
     rollbacks = 0
     for seed in range(6):
         rng = np.random.default_rng(900 + seed)
