@@ -1060,3 +1060,35 @@ def test_covariance_chunks_roll_back_when_a_skipped_certificate_breaks():
         rollbacks += cs["rollbacks"]
         f.close()
     assert rollbacks > 0
+
+
+def test_handles_with_every_optional_buffer_are_created_and_destroyed_repeatedly():
+    """Graph replay + gradient cache (Gram columns, device mirrors, pinned staging) + observation weights +
+    a host exchange on the same process, 40 handles in a row: destruction releases everything (a leak or a
+    double free shows up as a HIP error or a crash long before 40), and the 40th solve equals the first."""
+    rng, X, Y = _problem(81, 2000, 300, 8)
+    w = rng.uniform(0.5, 2.0, size=2000)
+    o = cd.CDOptions(maxIter=2000, optTol=1e-11, randomize=False)
+    first = None
+    for it in range(40):
+        f = cd.CDLeastSquaresLoss(Y, X)
+        f.set_use_graph(True)
+        f.set_gradient_cache(3)
+        if it % 4 == 3:
+            f.set_host_exchange(lambda buf: None, 0, 1)          # a one-rank "transport": the seam with nothing behind it
+        x = cd.SparseIterate(300)
+        for lam in (0.3, 0.15, 0.08):
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam), o)
+        assert f.cache_stats()["gram_columns"] > 0
+        first = x.dense().copy() if first is None else first
+        np.testing.assert_allclose(x.dense(), first, rtol=0, atol=1e-12)
+        f.close()
+        fw = cd.CDWeightedLSLoss(Y, X, w)
+        xw = cd.SparseIterate(300)
+        cd.coordinateDescent_(xw, fw, cd.ProxL1(0.1), o)
+        fw.close()
+    xo = O.SparseIterate(300)
+    fo = O.CDLeastSquaresLoss(Y, X)
+    for lam in (0.3, 0.15, 0.08):
+        O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(maxIter=2000, optTol=1e-11, randomize=False))
+    np.testing.assert_allclose(first, xo.dense(), rtol=0, atol=BETA_TOL)
