@@ -11,6 +11,21 @@
 void gc_fold(cdh_handle h);
 int32_t finish_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH);
 
+// On row shards every rank must take the same turns (a rank that streams a chunk calls the exchange, a rank
+// that serves it from its cache does not): whatever depends on a local resource -- here: did the cache's
+// buffers fit on THIS device -- is agreed on through the exchange itself.  One rank: the local answer.
+int32_t all_ranks_agree(cdh_handle h, bool mine, bool* all) {
+    *all = mine;
+    if (!sharded(h) || h->nranks <= 1) return CDH_OK;
+    h->h_red[0] = mine ? 1.0 : 0.0;
+    HIPCHK(h, hipMemcpyAsync(h->d_red, h->h_red, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(allreduce(h, h->d_red, 1));
+    HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *all = h->h_red[0] == (double)h->nranks;
+    return CDH_OK;
+}
+
 // ---- gradient cache: the certified full pass -------------------------------------------------------------
 int32_t gc_size(cdh_handle h) {   // first use on this handle
     GradCache& c = h->gc;
@@ -23,9 +38,11 @@ int32_t gc_size(cdh_handle h) {   // first use on this handle
     if (c.beta_ok)
         for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) c.beta_ref[(size_t)h->x.coord(s_)] = h->x.slot_value(s_);
     const int64_t launches = (h->p + kCrossA - 1) / kCrossA;
-    if (hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec) != hipSuccess ||
-        hipMalloc((void**)&c.d_cols, sizeof(int64_t) * (p + kCrossA + kCrossB)) != hipSuccess) {
-        (void)hipGetLastError();      // no room for the cache's scratch: the handle keeps the dots-only screens
+    bool fits = hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec) == hipSuccess &&
+                hipMalloc((void**)&c.d_cols, sizeof(int64_t) * (p + kCrossA + kCrossB)) == hipSuccess;
+    if (!fits) (void)hipGetLastError();
+    CHK(all_ranks_agree(h, fits, &fits));
+    if (!fits) {                      // no room for the cache's scratch (on some rank): the dots-only screens stay
         c.mode = 0;
         c.g.clear(); c.g.shrink_to_fit();
         return CDH_OK;
@@ -44,20 +61,25 @@ int32_t gc_dev_upload(cdh_handle h) {
     GradCache& c = h->gc;
     if (!c.cov) return CDH_OK;
     const int64_t p = h->p, have = (int64_t)c.G.size();
-    // no room on the device for the mirrors is not an error: the visits simply stay in residual form
-    auto no_room = [&]() { (void)hipGetLastError(); c.cov = false; return (int32_t)CDH_OK; };
+    // no room on the device for the mirrors (on any rank) is not an error: the visits stay in residual form
     if (!c.d_g) {
-        if (hipMalloc((void**)&c.d_g, sizeof(double) * (size_t)p) != hipSuccess) return no_room();
-        if (hipMalloc((void**)&c.d_slot, sizeof(int32_t) * (size_t)p) != hipSuccess) return no_room();
-        // pinned staging for g on its way down and back (pageable copies are staged by the runtime, one
-        // hidden synchronisation each: two per chunk of visits)
-        if (hipHostMalloc((void**)&c.h_g_pin, sizeof(double) * 2 * (size_t)p) != hipSuccess) return no_room();
+        bool fits = hipMalloc((void**)&c.d_g, sizeof(double) * (size_t)p) == hipSuccess &&
+                    hipMalloc((void**)&c.d_slot, sizeof(int32_t) * (size_t)p) == hipSuccess &&
+                    // pinned staging for g on its way down and back (pageable copies are staged by the
+                    // runtime, one hidden synchronisation each: two per chunk of visits)
+                    hipHostMalloc((void**)&c.h_g_pin, sizeof(double) * 2 * (size_t)p) == hipSuccess;
+        if (!fits) (void)hipGetLastError();
+        CHK(all_ranks_agree(h, fits, &fits));
+        if (!fits) { c.cov = false; return CDH_OK; }
     }
     if (have > c.dev_slots_cap) {   // grow the store (64 columns at a time, at most kGcMaxBytes), keeping what is there
         const int64_t cap = std::min<int64_t>((have + 63) / 64 * 64 + 64, (int64_t)(kGcMaxBytes / sizeof(double)) / std::max<int64_t>(p, 1));
-        if (cap < have) { c.cov = false; return CDH_OK; }   // does not fit: the visits stay in residual form
+        if (cap < have) { c.cov = false; return CDH_OK; }   // does not fit (the same on every rank): residual form
         double* bigger = nullptr;
-        if (hipMalloc((void**)&bigger, sizeof(double) * (size_t)cap * (size_t)p) != hipSuccess) return no_room();
+        bool fits = hipMalloc((void**)&bigger, sizeof(double) * (size_t)cap * (size_t)p) == hipSuccess;
+        if (!fits) (void)hipGetLastError();
+        CHK(all_ranks_agree(h, fits, &fits));
+        if (!fits) { if (bigger) (void)hipFree(bigger); c.cov = false; return CDH_OK; }
         if (c.d_G && c.dev_slots > 0)
             HIPCHK(h, hipMemcpyAsync(bigger, c.d_G, sizeof(double) * (size_t)c.dev_slots * (size_t)p, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
