@@ -51,6 +51,45 @@ def profiled_traffic(kernel, rows, cols, dtype, block):
     return tab.get(f"{kernel}:n{rows}:p{cols}:{dtype}:B{block}")
 
 
+def measure_traffic_live(kernel, argv_tail, timeout_s=240):
+    """HBM bytes per launch of the dominant kernel on THIS box, measured now: two child runs of this very
+    script under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace domains, as
+    MI355X_MICROARCH.md prescribes), 1 warm-up + 2 timed steps each; KiB -> bytes, FETCH_SIZE doubled
+    (gfx950 counts 64 B per 128-B request of a wide coalesced read).  Returns (bytes, detail) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="cdh_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    out = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "c", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                   "--no-sparse", "--no-cfg1", "--no-cfg3", "--no-live-traffic"] + argv_tail
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if row["Counter_Name"] == counter and kernel in row["Kernel_Name"]]
+            if not vals:
+                return None, f"no {kernel} launches in the {counter} pass"
+            out[counter] = (sum(vals) / len(vals), len(vals))
+        fetch = 2.0 * 1024.0 * out["FETCH_SIZE"][0]
+        write = 1024.0 * out["WRITE_SIZE"][0]
+        return fetch + write, {"fetch_bytes": fetch, "write_bytes": write, "launches_counted": out["FETCH_SIZE"][1]}
+    except Exception as e:
+        return None, str(e)[:160]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def esz_of(dtype):
     import numpy as np
     return np.dtype(dtype).itemsize
@@ -258,6 +297,8 @@ def main():
                     help="with --exchange auto: skip the second region (same as --exchange rccl)")
     ap.add_argument("--no-cfg1", action="store_true", help="skip the cfg1 (n=1000, p=200) CPU-vs-GPU solve timing")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg3 (100-lambda path, n=2e6, p=5000) timing")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 --pmc child runs (the committed figure is used)")
     a = ap.parse_args()
 
     import numpy as np
@@ -503,6 +544,18 @@ def main():
         except Exception as e:
             res["cfg1"] = {"error": str(e)[:200]}
     f.close()
+    if cp.rank == 0 and cp.world == 1 and not a.no_live_traffic and not a.no_cpu_baseline:
+        # the 80 GB are released: the two counter passes (child processes) have the device to themselves
+        tail = ["--rows", str(a.rows), "--cols", str(a.cols), "--planted", str(a.planted), "--noise", str(a.noise),
+                "--dtype", a.dtype, "--mode", a.mode, "--block", str(a.block), "--lam-frac", str(a.lam_frac)]
+        live, detail = measure_traffic_live(kernel, tail)
+        if live is not None:
+            res["roofline"]["traffic"] = live
+            res["roofline"]["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this script on this "
+                                                 "box, just now (separate passes; KiB -> bytes, FETCH_SIZE x2)")
+            res["roofline"]["traffic_detail"] = detail
+        else:
+            res["roofline"]["traffic_live_error"] = detail
     default_workload = (a.rows, a.cols, a.dtype) == (10_000_000, 1000, "f64")
     if cp.rank == 0 and cp.world == 1 and default_workload and not a.no_cfg3 and not a.no_cpu_baseline:
         try:                               # the 80 GB of cfg2 are released: cfg3's 80 GB fit

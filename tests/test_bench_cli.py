@@ -18,7 +18,7 @@ def test_bench_options_do_not_collide_with_torchrun_abbreviations():
             "bench.py"]
     for o in opts:
         argv += [o] if o in ("--graph", "--no-cpu-baseline", "--no-sparse", "--no-rccl", "--no-exchange-trial",
-                             "--no-cfg1", "--no-cfg3") else [o, "1"]
+                             "--no-cfg1", "--no-cfg3", "--no-live-traffic") else [o, "1"]
     ns = get_args_parser().parse_args(argv)
     assert ns.training_script == "bench.py"
     assert ns.training_script_args == argv[argv.index("bench.py") + 1:]   # every option reached the script
