@@ -103,6 +103,8 @@ struct GradCache {
     int64_t dev_slots_cap = 0, dev_slots = 0;   // columns the device store can hold / holds
     int64_t cov_since_ref = 0;      // covariance-form visits since g was last taken from X itself
     std::vector<double> g_new;      // g as a covariance-form chunk left it, until the chunk is accepted
+    double q = 0.0;                 // r'r of the (virtual) residual g describes: sqrt-lasso thresholds and updates
+    bool q_valid = false;
     int64_t n_rollbacks = 0;
     int64_t n_validate = 0, n_batches = 0, n_columns = 0, n_certified = 0, n_exact = 0, n_passes = 0, n_cov = 0,
             n_reconcile = 0;
@@ -404,7 +406,7 @@ inline bool gc_applicable(const cdh_handle_s* h) {
 // g no longer describes r (y or the loss changed); with `columns` the Gram columns are gone too (X changed)
 void gc_invalidate(cdh_handle h, bool columns) {
     GradCache& c = h->gc;
-    c.valid = false; c.beta_ok = false;
+    c.valid = false; c.beta_ok = false; c.q_valid = false;
     for (int64_t j : c.moved) { c.dbeta[(size_t)j] = 0.0; c.in_moved[(size_t)j] = 0; }
     c.moved.clear();
     if (columns) {
@@ -433,6 +435,7 @@ void gc_after_rebuild(cdh_handle h) {
     }
     c.beta_ref.swap(nb);
     c.beta_ok = true;
+    c.q_valid = false;
 }
 // the streamed visits of a chunk have updated r: g learns of them at the next fold
 void gc_note_moves(cdh_handle h, const int64_t* idx0, int m) {
@@ -444,6 +447,7 @@ void gc_note_moves(cdh_handle h, const int64_t* idx0, int m) {
         if (hv != hv) { gc_invalidate(h, false); return; }   // a NaN step: nothing is known about r any more
         const int64_t k = idx0[i];
         if (c.beta_ok) c.beta_ref[(size_t)k] += hv;
+        c.q_valid = false;            // a streamed visit has changed r
         if (c.valid) {
             c.dbeta[(size_t)k] += hv;
             if (!c.in_moved[(size_t)k]) { c.in_moved[(size_t)k] = 1; c.moved.push_back(k); }

@@ -98,20 +98,36 @@ int32_t gc_dev_upload(cdh_handle h) {
 // fold, and a Gram column on the device for every coordinate of the chunk.
 bool cov_ok(cdh_handle h, const int64_t* idx0, int64_t m) {
     const GradCache& c = h->gc;
-    if (!c.cov || !c.valid || !c.moved.empty() || h->loss != CDH_LS || !gc_applicable(h) || !c.d_G) return false;
+    if (!c.cov || !c.valid || !c.moved.empty() || !gc_applicable(h) || !c.d_G) return false;
+    if (h->loss == CDH_SQRT && !c.q_valid) return false;
     if (c.dev_slots != (int64_t)c.G.size()) return false;
     for (int64_t i = 0; i < m; ++i) if (c.slot[(size_t)idx0[i]] < 0) return false;
     return true;
 }
 
+// r'r of the residual g describes, for the sqrt-lasso thresholds and updates: carried through the
+// covariance-form visits, re-read from r (one pass over r, after it has caught up) when a streamed visit,
+// a rebuild or a re-reference has changed r behind its back
+int32_t gc_ensure_q(cdh_handle h) {
+    GradCache& c = h->gc;
+    if (c.q_valid) return CDH_OK;
+    CHK(resid_moments_dev(h));
+    HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    c.q = h->h_red[1];
+    c.q_valid = true;
+    return CDH_OK;
+}
+
 // fold what can be folded, then ask cov_ok (the active passes of a solve call this before every chunk)
 bool gc_ready_for_cov(cdh_handle h, const int64_t* idx0, int64_t m) {
     GradCache& c = h->gc;
-    if (!c.cov || !c.valid || h->loss != CDH_LS || !c.d_G) return false;
+    if (!c.cov || !c.valid || !gc_applicable(h) || !c.d_G) return false;
     if (!c.moved.empty()) {
         for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return false;
         gc_fold(h);
     }
+    if (h->loss == CDH_SQRT && gc_ensure_q(h) != CDH_OK) return false;
     return cov_ok(h, idx0, m);
 }
 
@@ -124,7 +140,8 @@ template <int NG> int32_t launch_cov_chunk(cdh_handle h, int m) {
     GradCache& c = h->gc;
     for (int pos0 = 0; pos0 < m; pos0 += B) {
         const int nb = std::min(B, m - pos0);
-        hipLaunchKernelGGL((k_cov_record<NG>), dim3(1), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot, h->p, h->d_idx, pos0, nb, h->d_red);
+        hipLaunchKernelGGL((k_cov_record<NG>), dim3(1), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot, h->p, h->d_idx, pos0, nb,
+                           h->d_ctrl, h->d_red);
         hipLaunchKernelGGL((k_gram_scalar<NG>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb, h->chunk_dup ? 1 : 0, h->d_ctrl,
                            h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos0);
         hipLaunchKernelGGL(k_cov_gupdate, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot, h->p,
@@ -144,6 +161,7 @@ int32_t cov_run(cdh_handle h, const int64_t* idx0, int m) {
     HIPCHK(h, hipMemcpyAsync(c.d_g, c.h_g_pin, sizeof(double) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
     h->ctrl.maxH = 0.0;
     h->ctrl.domain_error = 0;
+    h->ctrl.q_carry = c.q;
     CHK(upload_ctrl(h));
     // the width of the handle's blocked sweep where it has one (same recurrence, same kernel), else 16
     const int B = (h->mode == CDH_SWEEP_BLOCK && h->blockB >= 16) ? h->blockB : 16;
@@ -175,6 +193,8 @@ void cov_accept_tail(cdh_handle h, int m, double* maxH) {
     GradCache& c = h->gc;
     const double mh = h->h_ctrl->maxH;
     if (mh > *maxH) *maxH = mh;
+    if (h->h_ctrl->domain_error) h->domain_error = true;
+    if (h->loss == CDH_SQRT) c.q = h->h_ctrl->q_carry;
     c.g.swap(c.g_new);
     c.n_cov += m;
     c.cov_since_ref += m;
@@ -352,10 +372,8 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     double rnorm = 0.0;
     auto refresh_rnorm = [&]() -> int32_t {
         if (h->loss != CDH_SQRT) return CDH_OK;
-        CHK(resid_moments_dev(h));
-        HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        rnorm = std::sqrt(h->h_red[1]);
+        CHK(gc_ensure_q(h));
+        rnorm = std::sqrt(c.q);
         return CDH_OK;
     };
     auto thr_of = [&](int64_t k) {
@@ -434,7 +452,7 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
         // a settled coordinate's certificate was read BEFORE the chunk's moves, it is re-checked afterwards
         // against the gradient as it stood when its turn came (the movers' columns are at hand).  A certificate
         // that no longer holds -- rare -- rolls the chunk back and reruns it up to that position.
-        if (c.cov && h->loss == CDH_LS && c.moved.empty() && c.d_G && c.dev_slots == (int64_t)c.G.size()) {
+        if (c.cov && c.moved.empty() && c.d_G && c.dev_slots == (int64_t)c.G.size() && (h->loss != CDH_SQRT || c.q_valid)) {
             std::vector<int64_t> upos;
             int64_t wend = pos;
             bool have_all = true;
@@ -452,6 +470,8 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
                     CHK(cov_run(h, vis.data(), mv));
                     // re-check the skipped positions in visit order, carrying g through the chunk's moves
                     std::vector<double> gv(c.g);
+                    double q_run = c.q;                  // sqrt-lasso: ||r|| moves with every visit, and the thresholds with it
+                    const double rnorm_before = rnorm;
                     int64_t bad = -1;
                     size_t iu = 0;
                     auto settled_at = [&](int64_t kq) {
@@ -461,20 +481,32 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
                         if (iu < upos.size() && upos[iu] == q) {
                             const double hv = h->h_hs[iu];
                             if (hv != 0.0) {
-                                const std::vector<double>& col = c.G[(size_t)c.slot[(size_t)vis[iu]]];
+                                const int64_t kv = vis[iu];
+                                if (h->loss == CDH_SQRT) {
+                                    q_run = q_run - 2.0 * hv * gv[(size_t)kv] + hv * hv * c.a[(size_t)kv];
+                                    if (q_run < 0.0) q_run = 0.0;
+                                    rnorm = std::sqrt(q_run);
+                                }
+                                const std::vector<double>& col = c.G[(size_t)c.slot[(size_t)kv]];
                                 for (int64_t kk = 0; kk < h->p; ++kk) gv[(size_t)kk] -= hv * col[(size_t)kk];
                             }
                             ++iu;
                         } else if (!settled_at(idx0[q])) { bad = q; break; }
                     }
+                    rnorm = rnorm_before;
                     if (bad < 0) {
                         iu = 0;
                         for (int64_t q = pos; q < wend; ++q) {      // bookkeeping in visit order
                             const int64_t kq = idx0[q];
                             if (iu < upos.size() && upos[iu] == q) { cov_apply_visit(h, kq, (int)iu); ++iu; c.n_exact += 1; }
-                            else { if (c.g[(size_t)kq] != 0.0) h->x.set(kq, 1.0); h->x.set(kq, 0.0); c.n_certified += 1; }
+                            else {   // settled: what the reference's SparseIterate would have seen (LS stores x[k] += b/a first)
+                                if (h->loss != CDH_SQRT && c.g[(size_t)kq] != 0.0) h->x.set(kq, 1.0);
+                                h->x.set(kq, 0.0);
+                                c.n_certified += 1;
+                            }
                         }
                         cov_accept_tail(h, mv, maxH);
+                        if (h->loss == CDH_SQRT) rnorm = std::sqrt(c.q);
                         break;
                     }
                     CHK(cov_reject(h, vis.data(), mv));

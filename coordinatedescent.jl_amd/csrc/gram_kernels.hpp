@@ -521,6 +521,7 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
         if (m > mh) mh = m;
         ctrl->maxH = mh;
         if (dom) ctrl->domain_error = 1;
+        if (loss == 1) ctrl->q_carry = q;   // r'r after the block's visits (every lane carries the same recurrence)
     }
     bool last = true;                                // last writer of a repeated coordinate wins
     if (dup) {
@@ -647,12 +648,14 @@ __global__ __launch_bounds__(64 * kGramWaves, CDH_CROSS_OCC) void k_cross(const 
 // the cache instead of being streamed from X: no HBM traffic for the visit at all.  k_cov_record gathers the
 // record of visits [pos0, pos0 + nb); k_gram_scalar runs the same B sequential updates as in the streamed
 // sweep; k_cov_gupdate then applies g -= sum_i h_i G_ki to all p entries.  The residual is brought up to
-// date later, once (k_multi_axpy over the coordinates that moved).  Least squares, fp64.
+// date later, once (k_multi_axpy over the coordinates that moved).  Least squares and sqrt-lasso (whose r'r
+// travels from block to block in the control block: q <- q - 2 h b + h^2 a, the recurrence the streamed
+// blocks use inside a block), fp64.
 template <int NG>
 __global__ __launch_bounds__(256) void k_cov_record(const double* __restrict__ g, const double* __restrict__ Gcols,
                                                     const int32_t* __restrict__ slot, int64_t p,
                                                     const int64_t* __restrict__ idx, int pos0, int nb,
-                                                    double* __restrict__ rec) {
+                                                    const Ctrl* ctrl, double* __restrict__ rec) {
     using R = GramRec<NG>;
     constexpr int B = R::B;
     __shared__ int64_t s_k[B];
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(256) void k_cov_record(const double* __restrict__ g
         if (sI <= j && j < nb) rec[R::g(sI, j)] = Gcols[s_off[j] + s_k[sI]];
     }
     for (int i = threadIdx.x; i < B; i += blockDim.x) rec[R::OFF_C + i] = (i < nb) ? g[s_k[i]] : 0.0;
-    if (threadIdx.x == 0) rec[R::OFF_Q] = 0.0;   // r'r: only the sqrt-lasso update reads it, and that one is streamed
+    if (threadIdx.x == 0) rec[R::OFF_Q] = ctrl->q_carry;   // r'r (read by the sqrt-lasso update only): carried, never re-read from r
 }
 
 __global__ void k_scatter_f64(double* __restrict__ dst, const int64_t* __restrict__ idx, const double* __restrict__ val, int m) {

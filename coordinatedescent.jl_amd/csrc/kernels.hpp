@@ -36,6 +36,7 @@ struct Ctrl {
     int32_t has_omega;
     int32_t domain_error;
     int32_t pad;
+    double q_carry;      // r'r carried from block to block by the covariance-form visits (sqrt-lasso)
 };
 
 // 16-byte native vectors (clang ext_vector_type: element access v[e] stays in registers and

@@ -205,7 +205,7 @@ int32_t cdh_set_screening(cdh_handle h, int32_t on);
  * Modes 1 and 2 engage only while n_total >= 400 * nnz(x): folding a move into the cached gradient is p host
  * flops, which beats re-reading X only on tall problems; mode 3 is mode 2 without that guard (tests).
  * Same iterates, support order and pass counts as visiting every coordinate.
- * While the cache is engaged the visits themselves need no read of X either (least squares): the block
+ * While the cache is engaged the visits themselves need no read of X either (least squares, sqrt-lasso): the block
  * record the scalar-update kernel consumes -- X_k'r, the Gram entries between the block's coordinates -- is
  * read off the cached gradient and Gram columns ("covariance form"), and r is brought up to date once, before
  * anything reads it and before any entry point returns.

@@ -1018,7 +1018,8 @@ def test_gradient_cache_default_mode_engages_on_tall_problems_only():
     f.close()
 
 
-def test_covariance_chunks_roll_back_when_a_skipped_certificate_breaks():
+@pytest.mark.parametrize("loss", ["ls", "sqrt"])
+def test_covariance_chunks_roll_back_when_a_skipped_certificate_breaks(loss):
     """Inside one covariance-form chunk the settled positions between two visits are skipped on the strength of
     certificates read BEFORE the chunk's moves.  On a design whose neighbouring columns are 0.97-correlated, a
     move flips its neighbour's certificate within the same chunk: the library must notice (it re-checks every
@@ -1037,8 +1038,11 @@ def test_covariance_chunks_roll_back_when_a_skipped_certificate_breaks():
             X[:, j] = 0.97 * X[:, j - 1] + np.sqrt(1 - 0.97 ** 2) * z[:, j]
         X = np.asfortranarray(X)
         Y = X[:, [20, 90, 91, 180]] @ np.array([2.0, -1.5, 1.0, 0.8]) + 0.5 * rng.standard_normal(n)
-        lam = 0.25
-        f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+        lam = 0.25 if loss == "ls" else 7.0         # sqrt-lasso: the threshold is lambda ||r||, with ||r|| ~ sqrt(n) / 2 here
+        if loss == "ls":
+            f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+        else:
+            f, fo = cd.CDSqrtLassoLoss(Y, X), O.CDSqrtLassoLoss(Y, X)
         f.set_sweep_mode("block", 16)
         f.set_gradient_cache(3)
         f.set_screening(2)
