@@ -102,6 +102,7 @@ struct GradCache {
     int32_t* d_slot = nullptr;
     int64_t dev_slots_cap = 0, dev_slots = 0;   // columns the device store can hold / holds
     int64_t cov_since_ref = 0;      // covariance-form visits since g was last taken from X itself
+    int64_t refresh_after = 0;      // ... after which it is (kGcCovRefresh; env CDH_GC_REFRESH for tests)
     std::vector<double> g_new;      // g as a covariance-form chunk left it, until the chunk is accepted
     double q = 0.0;                 // r'r of the (virtual) residual g describes: sqrt-lasso thresholds and updates
     bool q_valid = false;
@@ -970,6 +971,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->ks = env_int("CDH_KS", 0);
         h->gc.mode = std::max(0, std::min(3, env_int("CDH_GRADIENT_CACHE", 1)));
         h->gc.cov = env_int("CDH_GC_COV", 1) != 0;
+        h->gc.refresh_after = std::max(1, env_int("CDH_GC_REFRESH", (int)kGcCovRefresh));
         const int step_per_cu = std::max(1, env_int("CDH_STEP_GRID_PER_CU", 8));
         const int block_per_cu = std::max(1, std::min(kBlockGridPerCU, env_int("CDH_BLOCK_GRID_PER_CU", 3)));
         const int64_t want = (h->nvec + (int64_t)kBlock * kUnroll - 1) / ((int64_t)kBlock * kUnroll);

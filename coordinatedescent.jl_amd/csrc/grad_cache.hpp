@@ -353,19 +353,20 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     //    reference yet): one dots-only pass over X gives a fresh g instead
     // g has been carried through this many covariance-form updates without looking at X: take it afresh
     // (rounding only ever accumulates in g; one dots-only pass resets it)
-    if (c.valid && c.cov_since_ref > kGcCovRefresh) gc_invalidate(h, false);
+    // (re-referencing keeps what is known about beta: g will describe the same residual, only freshly summed)
+    const bool beta_known = c.beta_ok;
+    std::vector<double> beta_keep;
+    if (beta_known) beta_keep = c.beta_ref;
+    if (c.valid && c.cov_since_ref > c.refresh_after) gc_invalidate(h, false);
     std::vector<int64_t> want;
     if (c.valid) {
         for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) want.push_back(j);
         if ((int)want.size() > kGcMaxFetch) { gc_invalidate(h, false); want.clear(); }
     }
     if (!c.valid) {
-        const bool ok = c.beta_ok;
-        std::vector<double> keep;
-        if (ok) keep = c.beta_ref;
         CHK(gc_validate(h));
-        c.beta_ok = ok;
-        if (ok) c.beta_ref.swap(keep);
+        c.beta_ok = beta_known;
+        if (beta_known) c.beta_ref.swap(beta_keep);
     }
     for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_)       // the support moves in every pass: its columns first
         if (c.slot[(size_t)h->x.coord(s_)] < 0) want.push_back(h->x.coord(s_));

@@ -1096,3 +1096,29 @@ def test_handles_with_every_optional_buffer_are_created_and_destroyed_repeatedly
     for lam in (0.3, 0.15, 0.08):
         O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(maxIter=2000, optTol=1e-11, randomize=False))
     np.testing.assert_allclose(first, xo.dense(), rtol=0, atol=BETA_TOL)
+
+
+@pytest.mark.parametrize("loss", ["ls", "sqrt"])
+def test_gradient_cache_rereferences_from_x_without_losing_track(monkeypatch, loss):
+    """After enough covariance-form visits the cached gradient is re-read from X (rounding only ever
+    accumulates in it).  With the interval cut to 40 visits a 10-lambda path re-references many times: same
+    beta, support order and pass counts as the oracle throughout, and warm starts from the SAME x afterwards
+    (the Julia binding's call pattern: set_iterate + rebuild) must not cost another reference pass each."""
+    monkeypatch.setenv("CDH_GC_REFRESH", "40")
+    rng, X, Y = _problem(71, 3000, 400, 10)
+    top = 3.4 if loss == "sqrt" else 0.3
+    lams = np.exp(np.linspace(np.log(top), np.log((0.65 if loss == "sqrt" else 0.15) * top), 10))
+    o = dict(maxIter=3000, optTol=1e-10, randomize=False)
+    cls, ocls = (cd.CDSqrtLassoLoss, O.CDSqrtLassoLoss) if loss == "sqrt" else (cd.CDLeastSquaresLoss, O.CDLeastSquaresLoss)
+    f, fo = cls(Y, X), ocls(Y, X)
+    f.set_gradient_cache(3)
+    x, xo = cd.SparseIterate(400), O.SparseIterate(400)
+    for lam in lams:
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))      # x is pushed back each time: set_iterate + rebuild
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"]
+    cs = f.cache_stats()
+    assert cs["covariance_visits"] > 400 and 3 <= cs["reference_passes"] <= 2 + cs["covariance_visits"] // 40, cs
+    np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-9)
+    f.close()
