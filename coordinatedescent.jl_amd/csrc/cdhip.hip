@@ -94,7 +94,9 @@ struct GradCache {
     std::vector<int32_t> slot;      // coordinate -> Gram column, -1 = not cached
     std::vector<std::vector<double>> G;
     double* d_cross = nullptr;      // device: ceil(p / 64) records of 64 x 32 cross products
-    int64_t* d_cols = nullptr;      // device: 0 .. p-1 (A operand lists) followed by the B columns of a batch
+    double* d_cross_part = nullptr; // device: the same per row-slab block (cross_J of them per column group)
+    int cross_J = 1, cross_GX = 1;
+    int64_t* d_cols = nullptr;      // device: the B columns of a batch
     std::vector<double> h_cross;
     // covariance-form visits: device mirrors of g, the Gram columns (slot-major, p doubles each) and the slot map
     bool cov = true;                // env CDH_GC_COV
@@ -898,6 +900,7 @@ void free_all(cdh_handle h) {
     if (h->d_p2p_base) (void)hipFree(h->d_p2p_base);
     if (h->gc.d_cross) (void)hipFree(h->gc.d_cross);
     if (h->gc.d_cols) (void)hipFree(h->gc.d_cols);
+    if (h->gc.d_cross_part) (void)hipFree(h->gc.d_cross_part);
     if (h->gc.d_g) (void)hipFree(h->gc.d_g);
     if (h->gc.d_G) (void)hipFree(h->gc.d_G);
     if (h->gc.d_slot) (void)hipFree(h->gc.d_slot);
@@ -1006,7 +1009,6 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
                                                 (size_t)cus * kBlockGridPerCU * BlockRec<kMaxBlockB>::N,
                                                 (size_t)4096 * kColChunks * 2,
                                                 (size_t)cus * 2 * GramRec<4>::N,
-                                                (size_t)cus * 2 * kCrossRec,
                                                 (size_t)cus * std::max(h->gram32_per_cu, 4) * GramRec<2>::N,
                                                 (size_t)cus * 4 * GramRec<1>::N});
         HIPCHK(h, hipMalloc(&h->d_partials, sizeof(double) * h->partials_doubles));

@@ -37,9 +37,17 @@ int32_t gc_size(cdh_handle h) {   // first use on this handle
     c.beta_ok = h->r_consistent;          // r == y - X * (the handle's iterate) right now?
     if (c.beta_ok)
         for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) c.beta_ref[(size_t)h->x.coord(s_)] = h->x.slot_value(s_);
-    const int64_t launches = (h->p + kCrossA - 1) / kCrossA;
+    // one k_cross launch per batch: a block per (group of 64 columns, j of J), about two resident blocks per CU
+    const int64_t launches = (h->p + kCrossA - 1) / kCrossA;      // column groups
+    const int64_t nslabs = (h->nvec + kCrossSlab - 1) / kCrossSlab;
+    // gridDim.x = column groups in flight (env CDH_CROSS_GX, default 16), gridDim.y = row lanes; never more blocks
+    // than stay resident, 2 per CU (a partly filled second round would double the time)
+    const char* gxe = getenv("CDH_CROSS_GX");
+    c.cross_GX = (int)std::max<int64_t>(1, std::min<int64_t>(launches, gxe ? atoi(gxe) : 16));
+    c.cross_J = (int)std::max<int64_t>(1, std::min<int64_t>(nslabs, (2 * (int64_t)h->cus) / c.cross_GX));
     bool fits = hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec) == hipSuccess &&
-                hipMalloc((void**)&c.d_cols, sizeof(int64_t) * (p + kCrossA + kCrossB)) == hipSuccess;
+                hipMalloc((void**)&c.d_cross_part, sizeof(double) * (size_t)launches * (size_t)c.cross_J * kCrossRec) == hipSuccess &&
+                hipMalloc((void**)&c.d_cols, sizeof(int64_t) * kCrossB) == hipSuccess;
     if (!fits) (void)hipGetLastError();
     CHK(all_ranks_agree(h, fits, &fits));
     if (!fits) {                      // no room for the cache's scratch (on some rank): the dots-only screens stay
@@ -47,9 +55,6 @@ int32_t gc_size(cdh_handle h) {   // first use on this handle
         c.g.clear(); c.g.shrink_to_fit();
         return CDH_OK;
     }
-    std::vector<int64_t> ident(p + kCrossA + kCrossB, 0);
-    for (size_t k = 0; k < p; ++k) ident[k] = (int64_t)k;
-    HIPCHK(h, hipMemcpy(c.d_cols, ident.data(), sizeof(int64_t) * ident.size(), hipMemcpyHostToDevice));
     c.h_cross.assign((size_t)launches * kCrossRec, 0.0);
     return CDH_OK;
 }
@@ -247,24 +252,18 @@ int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
         c.mode = 0;                       // this problem's supports do not fit: plain screens from now on
         return CDH_OK;
     }
-    const int64_t launches = (h->p + kCrossA - 1) / kCrossA;
-    const int G = NGgrid(h, 4);
-    if ((size_t)G * kCrossRec > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partial buffer too small for the cross-product grid");
+    const int64_t launches = (h->p + kCrossA - 1) / kCrossA;      // column groups
     for (size_t b0 = 0; b0 < todo.size(); b0 += kCrossB) {
         const int nbc = (int)std::min<size_t>(kCrossB, todo.size() - b0);
-        int64_t* d_b = c.d_cols + h->p + kCrossA;
-        HIPCHK(h, hipMemcpyAsync(d_b, todo.data() + b0, sizeof(int64_t) * (size_t)nbc, hipMemcpyHostToDevice, h->stream));
-        for (int64_t L = 0; L < launches; ++L) {
-            const int na = (int)std::min<int64_t>(kCrossA, h->p - L * kCrossA);
-            CHK(dispatch(h, [&](auto* t) {
-                using T = std::remove_pointer_t<decltype(t)>;
-                hipLaunchKernelGGL(k_cross<T>, dim3(G), dim3(64 * kGramWaves), 0, h->stream, (const T*)h->X, h->ld, h->nvec,
-                                   c.d_cols + L * kCrossA, na, d_b, nbc, h->d_partials);
-                return CDH_OK;
-            }));
-            hipLaunchKernelGGL(k_gram_reduce, dim3(kCrossRec / kReduceVals), dim3(64 * kReduceWaves), 0, h->stream,
-                               h->d_partials, G, kCrossRec, c.d_cross + L * kCrossRec);
-        }
+        HIPCHK(h, hipMemcpyAsync(c.d_cols, todo.data() + b0, sizeof(int64_t) * (size_t)nbc, hipMemcpyHostToDevice, h->stream));
+        CHK(dispatch(h, [&](auto* t) {
+            using T = std::remove_pointer_t<decltype(t)>;
+            hipLaunchKernelGGL(k_cross<T>, dim3((unsigned)c.cross_GX, (unsigned)c.cross_J), dim3(64 * kGramWaves), 0, h->stream,
+                               (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc, c.d_cross_part);
+            return CDH_OK;
+        }));
+        hipLaunchKernelGGL(k_cross_reduce, dim3(kCrossRec / 256, (unsigned)launches), dim3(256), 0, h->stream, c.d_cross_part,
+                           c.cross_J, c.d_cross);
         HIPCHK(h, hipGetLastError());
         CHK(allreduce(h, c.d_cross, (size_t)launches * kCrossRec));
         HIPCHK(h, hipMemcpyAsync(c.h_cross.data(), c.d_cross, sizeof(double) * (size_t)launches * kCrossRec,

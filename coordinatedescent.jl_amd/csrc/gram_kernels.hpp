@@ -538,94 +538,107 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
     }
 }
 
-// Cross products of up to 64 columns (A) with up to 32 columns (B) in one pass over both sets:
-//   partials[block][(2 ta + tb) * 256 + i * 16 + j] = X_{A[16 ta + i]}' X_{B[16 tb + j]}   (this block's rows)
+// Cross products of ALL p columns with up to 32 columns (B) in ONE launch, one pass over X:
+//   out[cg][(2 ta + tb) * 256 + i * 16 + j] = X_{64 cg + 16 ta + i}' X_{B[16 tb + j]}
 // The Gram COLUMNS the gradient cache keeps for the coordinates that move (cdhip.hip, GradCache): with
 // G_j = X'X_j for every moved j, X_k'r is known for every k without reading X again.  Same use of the
 // matrix pipe as k_gramstep -- a 16 x 16 fp64 accumulator tile in 8 registers, rows of X as the K
 // dimension, lane (c, g) loading 16 bytes of column c at vector 4u + g -- with separate A and B operands
-// (4 x 2 tiles).  (64 + nb) columns read for 64 x nb products -- B columns that are not asked for are not
-// loaded -- i.e. 1.5 passes over X per 32 Gram columns.  Measured on cfg3 (n = 2e6: 237 launches x 355 us =
-// 84 ms for 96 columns, 4.3 TB/s, matrix pipe ~1/3 busy): neither HBM nor the pipe is saturated, and the
-// total does not move with 6 or 8 A tiles per launch, 1 / 2 / 4 vector rows of loads in flight or 3 waves
-// per SIMD, nor with the next group of loads requested before the current group's MFMAs (software
-// pipelining, two groups in flight: 85.5 against 84.8 ms) (tools/cross_scan.sh: 82 .. 92 ms).  The launches
-// are short -- 7.6 chunks per wave at 2e6 rows -- and cost what the fixed + rows / bandwidth model of the
-// Gram kernel predicts to within 15 %.  fp32 storage is widened to fp64 on the way in (an occasional pass,
-// not the sweep).
-#ifndef CDH_CROSS_TA
-#define CDH_CROSS_TA 4
-#endif
+// (4 x 2 tiles).  Grid: blockIdx.x = lane of column groups (64 consecutive columns each; the block walks the
+// groups x, x + gridDim.x, ... one after the other), blockIdx.y = row lane (the block takes the row slabs y,
+// y + gridDim.y, ... of 1024 vectors); a record per (group, row lane), summed by k_cross_reduce.  X is
+// streamed once (non-temporal); the 32 B columns are re-read by every column group but come out of L2 /
+// Infinity Cache (temporal loads).  Counters on cfg3 (n = 2e6, p = 5000; one launch per batch of 32 columns):
+// FETCH_SIZE 74 GB per launch -- X once, the B columns are not re-fetched --, MfmaUtil 39 %, MemUnitStalled
+// 0: 22 .. 24 ms per launch = 3.3 .. 3.6 TB/s of X, the same at 1e7 x 1000, 2e6 x 5000 and 5e5 x 20000
+// (tools/cross_rate.py).  Round 2's first version (one launch per column group, B re-read from HBM: 1.5
+// passes over X per batch in 79 launches) took 28 ms per batch; neither version moves with tile counts, loads
+// in flight (1 / 2 / 4 vector rows), occupancy (2 / 3 / 4 waves per SIMD), software-pipelined loads or the
+// number of column groups in flight (1 .. 79) (tools/cross_scan.sh).  What binds it is the volume of loads
+// through the CUs' vector-memory path, ~5 TB/s in total: the B fragments come from L2 but still have to be
+// loaded, 32 columns for every 64 of X.  Staging the B chunk of a block in LDS once, four waves on four
+// different column groups sharing it, would take it to 1.125 loads per byte of X: what is left to do.
+// fp32 storage is widened to fp64 on the way in (an occasional pass, not the sweep).
 #ifndef CDH_CROSS_UH
 #define CDH_CROSS_UH 2
 #endif
 #ifndef CDH_CROSS_OCC
 #define CDH_CROSS_OCC 2
 #endif
-constexpr int kCrossTA = CDH_CROSS_TA, kCrossTB = 2, kCrossA = 16 * kCrossTA, kCrossB = 16 * kCrossTB,
+constexpr int kCrossTA = 4, kCrossTB = 2, kCrossA = 16 * kCrossTA, kCrossB = 16 * kCrossTB,
               kCrossRec = kCrossTA * kCrossTB * 256;
 constexpr int kCrossUH = CDH_CROSS_UH;   // vector rows of fragment loads in flight per group
+constexpr int kCrossSlab = 1024;         // vectors per row slab (fp64: 2048 rows)
 template <typename T>
 __global__ __launch_bounds__(64 * kGramWaves, CDH_CROSS_OCC) void k_cross(const T* __restrict__ X, int64_t ld, int64_t nvec,
-                                                              const int64_t* __restrict__ acols, int na,
-                                                              const int64_t* __restrict__ bcols, int nbc,
-                                                              double* __restrict__ partials) {
+                                                                        int64_t p, const int64_t* __restrict__ bcols,
+                                                                        int nbc, double* __restrict__ partials) {
     using V = typename VecOf<T>::V;
     constexpr int NV = VecOf<T>::N;
     __shared__ double s_red[kGramWaves][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const V* av[kCrossTA];
     const V* bv[kCrossTB];
-    bool aact[kCrossTA], bact[kCrossTB];
-#pragma unroll
-    for (int grp = 0; grp < kCrossTA; ++grp) {
-        const int i = 16 * grp + c;
-        aact[grp] = i < na;
-        av[grp] = reinterpret_cast<const V*>(X + acols[aact[grp] ? i : 0] * ld);
-    }
+    bool bact[kCrossTB];
 #pragma unroll
     for (int grp = 0; grp < kCrossTB; ++grp) {
         const int j = 16 * grp + c;
         bact[grp] = j < nbc;
         bv[grp] = reinterpret_cast<const V*>(X + bcols[bact[grp] ? j : 0] * ld);
     }
+    const int64_t nslabs = (nvec + kCrossSlab - 1) / kCrossSlab;
+    const int64_t ngroups = (p + kCrossA - 1) / kCrossA;
+    // only gridDim.x column groups are in flight at any time (few distinct column streams, hence pages, across
+    // the chip); the block walks its share of the groups one after the other, a record per (group, row lane)
+    for (int64_t cg = blockIdx.x; cg < ngroups; cg += gridDim.x) {
+    const int64_t a0 = cg * kCrossA;
+    const V* av[kCrossTA];
+    bool aact[kCrossTA];
+#pragma unroll
+    for (int grp = 0; grp < kCrossTA; ++grp) {
+        const int64_t col = a0 + 16 * grp + c;
+        aact[grp] = col < p;
+        av[grp] = reinterpret_cast<const V*>(X + (aact[grp] ? col : a0) * ld);
+    }
     dvec4 tile[kCrossTA * kCrossTB];
 #pragma unroll
     for (int t = 0; t < kCrossTA * kCrossTB; ++t) tile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
-    const int64_t nchunks = (nvec + 63) / 64;
-    for (int64_t ch = (int64_t)wave * gridDim.x + blockIdx.x; ch < nchunks; ch += (int64_t)gridDim.x * kGramWaves) {
-        const int64_t v0 = ch * 64;
+    for (int64_t slab = blockIdx.y; slab < nslabs; slab += gridDim.y) {
+        for (int ch = wave; ch < kCrossSlab / 64; ch += kGramWaves) {
+            const int64_t v0 = slab * kCrossSlab + (int64_t)ch * 64;
+            if (v0 >= nvec) break;
 #pragma unroll 1
-        for (int u0 = 0; u0 < 16; u0 += kCrossUH) {
-            V xa[kCrossUH][kCrossTA], xb[kCrossUH][kCrossTB];
+            for (int u0 = 0; u0 < 16; u0 += kCrossUH) {
+                V xa[kCrossUH][kCrossTA], xb[kCrossUH][kCrossTB];
 #pragma unroll
-            for (int u = 0; u < kCrossUH; ++u) {
-                const int64_t v = v0 + 4 * (u0 + u) + g;
-                const bool in = v < nvec;
+                for (int u = 0; u < kCrossUH; ++u) {
+                    const int64_t v = v0 + 4 * (u0 + u) + g;
+                    const bool in = v < nvec;
 #pragma unroll
-                for (int grp = 0; grp < kCrossTB; ++grp)
-                    xb[u][grp] = (bact[grp] && in) ? ld_stream<true>(bv[grp] + v) : vzero((V*)nullptr);
+                    for (int grp = 0; grp < kCrossTB; ++grp)   // shared by every column group: let the caches keep it
+                        xb[u][grp] = (bact[grp] && in) ? ld_stream<false>(bv[grp] + v) : vzero((V*)nullptr);
 #pragma unroll
-                for (int grp = 0; grp < kCrossTA; ++grp)
-                    xa[u][grp] = (aact[grp] && in) ? ld_stream<true>(av[grp] + v) : vzero((V*)nullptr);
-            }
-#pragma unroll
-            for (int u = 0; u < kCrossUH; ++u)
-#pragma unroll
-                for (int e = 0; e < NV; ++e) {
-                    double b[kCrossTB];
-#pragma unroll
-                    for (int gb = 0; gb < kCrossTB; ++gb) b[gb] = (double)xb[u][gb][e];
-#pragma unroll
-                    for (int ga = 0; ga < kCrossTA; ++ga) {
-                        const double a = (double)xa[u][ga][e];
-#pragma unroll
-                        for (int gb = 0; gb < kCrossTB; ++gb)
-                            tile[ga * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[gb], tile[ga * kCrossTB + gb], 0, 0, 0);
-                    }
+                    for (int grp = 0; grp < kCrossTA; ++grp)
+                        xa[u][grp] = (aact[grp] && in) ? ld_stream<true>(av[grp] + v) : vzero((V*)nullptr);
                 }
+#pragma unroll
+                for (int u = 0; u < kCrossUH; ++u)
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) {
+                        double b[kCrossTB];
+#pragma unroll
+                        for (int gb = 0; gb < kCrossTB; ++gb) b[gb] = (double)xb[u][gb][e];
+#pragma unroll
+                        for (int ga = 0; ga < kCrossTA; ++ga) {
+                            const double a = (double)xa[u][ga][e];
+#pragma unroll
+                            for (int gb = 0; gb < kCrossTB; ++gb)
+                                tile[ga * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[gb], tile[ga * kCrossTB + gb], 0, 0, 0);
+                        }
+                    }
+            }
         }
     }
+    double* __restrict__ out = partials + (cg * gridDim.y + blockIdx.y) * kCrossRec;
 #pragma unroll
     for (int t = 0; t < kCrossTA * kCrossTB; ++t) {
 #pragma unroll
@@ -636,10 +649,21 @@ __global__ __launch_bounds__(64 * kGramWaves, CDH_CROSS_OCC) void k_cross(const 
             double sum = 0.0;
 #pragma unroll
             for (int wv = 0; wv < kGramWaves; ++wv) sum += s_red[wv][v];
-            partials[(int64_t)blockIdx.x * kCrossRec + t * 256 + v] = sum;
+            out[t * 256 + v] = sum;
         }
         __syncthreads();
     }
+    }   // cg
+}
+// out[cg][v] = sum over the J row-slab records of column group cg, in a fixed order
+__global__ __launch_bounds__(256) void k_cross_reduce(const double* __restrict__ partials, int J, double* __restrict__ out) {
+    const int v = blockIdx.x * 256 + threadIdx.x;          // < kCrossRec
+    const double* src = partials + (int64_t)blockIdx.y * J * kCrossRec + v;
+    double s0 = 0.0, s1 = 0.0;
+    int j = 0;
+    for (; j + 1 < J; j += 2) { s0 += src[(int64_t)j * kCrossRec]; s1 += src[(int64_t)(j + 1) * kCrossRec]; }
+    if (j < J) s0 += src[(int64_t)j * kCrossRec];
+    out[(int64_t)blockIdx.y * kCrossRec + v] = s0 + s1;
 }
 
 // ---- covariance-form visits (cdhip.hip / grad_cache.hpp, "cov chunks") --------------------------------------

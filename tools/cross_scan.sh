@@ -1,6 +1,6 @@
 #!/bin/bash
 # k_cross tuning: kernel-trace total of the cfg3 path's Gram-column batches for each library build under exp_build/
-# (hipcc -DCDH_CROSS_TA=.. -DCDH_CROSS_UH=.. -DCDH_CROSS_OCC=..).  usage: tools/cross_scan.sh
+# (hipcc -D-DCDH_CROSS_UH=.. -DCDH_CROSS_OCC=..).  usage: tools/cross_scan.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/prof
 cd /tmp && export TMPDIR=/tmp
