@@ -40,10 +40,11 @@ int32_t gc_size(cdh_handle h) {   // first use on this handle
     // one k_cross launch per batch: a block per (group of 64 columns, j of J), about two resident blocks per CU
     const int64_t launches = (h->p + kCrossA - 1) / kCrossA;      // column groups
     const int64_t nslabs = (h->nvec + kCrossSlab - 1) / kCrossSlab;
-    // gridDim.x = column groups in flight (env CDH_CROSS_GX, default 16), gridDim.y = row lanes; never more blocks
+    // gridDim.x = column groups in flight (super-groups of 4 x 64 columns; env CDH_CROSS_GX, default 4), gridDim.y = row lanes; never more blocks
     // than stay resident, 2 per CU (a partly filled second round would double the time)
     const char* gxe = getenv("CDH_CROSS_GX");
-    c.cross_GX = (int)std::max<int64_t>(1, std::min<int64_t>(launches, gxe ? atoi(gxe) : 16));
+    const int64_t nsuper = (launches + kGramWaves - 1) / kGramWaves;   // a block's four waves take four column groups
+    c.cross_GX = (int)std::max<int64_t>(1, std::min<int64_t>(nsuper, gxe ? atoi(gxe) : 4));
     c.cross_J = (int)std::max<int64_t>(1, std::min<int64_t>(nslabs, (2 * (int64_t)h->cus) / c.cross_GX));
     bool fits = hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec) == hipSuccess &&
                 hipMalloc((void**)&c.d_cross_part, sizeof(double) * (size_t)launches * (size_t)c.cross_J * kCrossRec) == hipSuccess &&
@@ -253,8 +254,10 @@ int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
         return CDH_OK;
     }
     const int64_t launches = (h->p + kCrossA - 1) / kCrossA;      // column groups
-    for (size_t b0 = 0; b0 < todo.size(); b0 += kCrossB) {
-        const int nbc = (int)std::min<size_t>(kCrossB, todo.size() - b0);
+    const char* bmax = getenv("CDH_CROSS_BATCH");      // experiments: fewer B columns per launch (16: one tile column)
+    const size_t batch = (size_t)std::max(1, std::min(kCrossB, bmax ? atoi(bmax) : kCrossB));
+    for (size_t b0 = 0; b0 < todo.size(); b0 += batch) {
+        const int nbc = (int)std::min<size_t>(batch, todo.size() - b0);
         HIPCHK(h, hipMemcpyAsync(c.d_cols, todo.data() + b0, sizeof(int64_t) * (size_t)nbc, hipMemcpyHostToDevice, h->stream));
         CHK(dispatch(h, [&](auto* t) {
             using T = std::remove_pointer_t<decltype(t)>;

@@ -544,20 +544,22 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
 // G_j = X'X_j for every moved j, X_k'r is known for every k without reading X again.  Same use of the
 // matrix pipe as k_gramstep -- a 16 x 16 fp64 accumulator tile in 8 registers, rows of X as the K
 // dimension, lane (c, g) loading 16 bytes of column c at vector 4u + g -- with separate A and B operands
-// (4 x 2 tiles).  Grid: blockIdx.x = lane of column groups (64 consecutive columns each; the block walks the
-// groups x, x + gridDim.x, ... one after the other), blockIdx.y = row lane (the block takes the row slabs y,
-// y + gridDim.y, ... of 1024 vectors); a record per (group, row lane), summed by k_cross_reduce.  X is
-// streamed once (non-temporal); the 32 B columns are re-read by every column group but come out of L2 /
-// Infinity Cache (temporal loads).  Counters on cfg3 (n = 2e6, p = 5000; one launch per batch of 32 columns):
-// FETCH_SIZE 74 GB per launch -- X once, the B columns are not re-fetched --, MfmaUtil 39 %, MemUnitStalled
-// 0: 22 .. 24 ms per launch = 3.3 .. 3.6 TB/s of X, the same at 1e7 x 1000, 2e6 x 5000 and 5e5 x 20000
-// (tools/cross_rate.py).  Round 2's first version (one launch per column group, B re-read from HBM: 1.5
-// passes over X per batch in 79 launches) took 28 ms per batch; neither version moves with tile counts, loads
-// in flight (1 / 2 / 4 vector rows), occupancy (2 / 3 / 4 waves per SIMD), software-pipelined loads or the
-// number of column groups in flight (1 .. 79) (tools/cross_scan.sh).  What binds it is the volume of loads
-// through the CUs' vector-memory path, ~5 TB/s in total: the B fragments come from L2 but still have to be
-// loaded, 32 columns for every 64 of X.  Staging the B chunk of a block in LDS once, four waves on four
-// different column groups sharing it, would take it to 1.125 loads per byte of X: what is left to do.
+// (4 x 2 tiles per wave).  Grid: blockIdx.x = lane of SUPER-groups (256 consecutive columns: one group of 64 per
+// wave; the block walks the super-groups x, x + gridDim.x, ... one after the other), blockIdx.y = row lane (the
+// block takes the row slabs y, y + gridDim.y, ... of 1024 vectors, 64 vectors at a time, all four waves on the
+// same chunk); a record per (column group, row lane), summed by k_cross_reduce.  X is streamed once
+// (non-temporal fragment loads); the block's B chunk -- 32 columns x 64 vectors -- is loaded once, fully
+// coalesced, into LDS (double-buffered: the next chunk's loads are in flight during this chunk's MFMAs) and read
+// from there by all four waves.
+// How it got here (cfg3: n = 2e6, p = 5000; per batch of 32 columns).  v1, one launch per column group with B
+// fragments loaded from HBM by every launch: 79 launches, 28 ms.  v2, one launch, B fragments re-read out of L2
+// by every column group (temporal loads): FETCH_SIZE 74 GB = X once, yet 22 .. 24 ms = 3.3 .. 3.6 TB/s of X at
+// 1e7 x 1000, 2e6 x 5000 and 5e5 x 20000 alike, MfmaUtil 39 %, MemUnitStalled 0, unmoved by tile counts, loads
+// in flight, occupancy, software pipelining or column groups in flight (tools/cross_scan.sh, cross_rate.py) --
+// but 18 ms with 16 B columns and 17 ms with 8: what bound it was the volume of loads through the CUs'
+// vector-memory path (~5 TB/s in total), a third of which were B fragments coming from L2.  Hence B through LDS:
+// 20 ms per batch = 4.0 TB/s of X, MfmaUtil 47 % (2 vector rows of fragment loads in flight: 1 gives 24.7 ms, 4
+// gives 21.4 ms; 1, 2 or 4 super-groups in flight alike, 8 slower).  What is left is the fragment-shaped A loads.
 // fp32 storage is widened to fp64 on the way in (an occasional pass, not the sweep).
 #ifndef CDH_CROSS_UH
 #define CDH_CROSS_UH 2
@@ -569,91 +571,117 @@ constexpr int kCrossTA = 4, kCrossTB = 2, kCrossA = 16 * kCrossTA, kCrossB = 16 
               kCrossRec = kCrossTA * kCrossTB * 256;
 constexpr int kCrossUH = CDH_CROSS_UH;   // vector rows of fragment loads in flight per group
 constexpr int kCrossSlab = 1024;         // vectors per row slab (fp64: 2048 rows)
+constexpr int kCrossXS = 64 + 2;          // LDS column stride of the B chunk in 16-byte slots (pad 2: conflict-free fragment reads)
 template <typename T>
 __global__ __launch_bounds__(64 * kGramWaves, CDH_CROSS_OCC) void k_cross(const T* __restrict__ X, int64_t ld, int64_t nvec,
                                                                         int64_t p, const int64_t* __restrict__ bcols,
                                                                         int nbc, double* __restrict__ partials) {
     using V = typename VecOf<T>::V;
     constexpr int NV = VecOf<T>::N;
+    // the block's B chunk (32 columns x 64 vectors), double-buffered: loaded once per chunk, fully coalesced
+    // (a wave instruction = 64 consecutive vectors of one column), and shared by the four waves, each of which
+    // works on a DIFFERENT group of 64 X columns -- so the B fragments reach the matrix pipe through LDS and
+    // the vector-memory path carries (256 + 32) columns per 256 of X instead of (64 + 32) per 64
+    __shared__ V s_b[2][kCrossB * kCrossXS];
     __shared__ double s_red[kGramWaves][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const V* bv[kCrossTB];
-    bool bact[kCrossTB];
+    const V* bld[kCrossB / kGramWaves];       // this thread's share of the cooperative B load: columns wave, wave + 4, ...
+    bool bact[kCrossB / kGramWaves];
 #pragma unroll
-    for (int grp = 0; grp < kCrossTB; ++grp) {
-        const int j = 16 * grp + c;
-        bact[grp] = j < nbc;
-        bv[grp] = reinterpret_cast<const V*>(X + bcols[bact[grp] ? j : 0] * ld);
+    for (int i = 0; i < kCrossB / kGramWaves; ++i) {
+        const int col = wave + kGramWaves * i;
+        bact[i] = col < nbc;
+        bld[i] = reinterpret_cast<const V*>(X + bcols[bact[i] ? col : 0] * ld);
     }
     const int64_t nslabs = (nvec + kCrossSlab - 1) / kCrossSlab;
-    const int64_t ngroups = (p + kCrossA - 1) / kCrossA;
-    // only gridDim.x column groups are in flight at any time (few distinct column streams, hence pages, across
-    // the chip); the block walks its share of the groups one after the other, a record per (group, row lane)
-    for (int64_t cg = blockIdx.x; cg < ngroups; cg += gridDim.x) {
-    const int64_t a0 = cg * kCrossA;
-    const V* av[kCrossTA];
-    bool aact[kCrossTA];
+    const int64_t ngroups = (p + kCrossA - 1) / kCrossA, nsuper = (ngroups + kGramWaves - 1) / kGramWaves;
+    constexpr int CPS = kCrossSlab / 64;      // chunks per slab
+    // chunk number q of this block's row lane -> first vector
+    auto chunk_v0 = [&](int64_t q) { return ((int64_t)blockIdx.y + (q / CPS) * gridDim.y) * kCrossSlab + (q % CPS) * 64; };
+    const int64_t my_slabs = nslabs > blockIdx.y ? (nslabs - blockIdx.y + gridDim.y - 1) / gridDim.y : 0;
+    const int64_t nq = my_slabs * CPS;
+    auto load_b = [&](V (&regs)[kCrossB / kGramWaves], int64_t q) {
+        const int64_t v = chunk_v0(q) + lane;
 #pragma unroll
-    for (int grp = 0; grp < kCrossTA; ++grp) {
-        const int64_t col = a0 + 16 * grp + c;
-        aact[grp] = col < p;
-        av[grp] = reinterpret_cast<const V*>(X + (aact[grp] ? col : a0) * ld);
-    }
-    dvec4 tile[kCrossTA * kCrossTB];
+        for (int i = 0; i < kCrossB / kGramWaves; ++i)
+            regs[i] = (bact[i] && v < nvec) ? ld_stream<false>(bld[i] + v) : vzero((V*)nullptr);
+    };
+    auto store_b = [&](const V (&regs)[kCrossB / kGramWaves], int buf) {
 #pragma unroll
-    for (int t = 0; t < kCrossTA * kCrossTB; ++t) tile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
-    for (int64_t slab = blockIdx.y; slab < nslabs; slab += gridDim.y) {
-        for (int ch = wave; ch < kCrossSlab / 64; ch += kGramWaves) {
-            const int64_t v0 = slab * kCrossSlab + (int64_t)ch * 64;
-            if (v0 >= nvec) break;
+        for (int i = 0; i < kCrossB / kGramWaves; ++i) s_b[buf][(wave + kGramWaves * i) * kCrossXS + lane] = regs[i];
+    };
+    // only gridDim.x super-groups (4 column groups each, one per wave) are in flight at any time; the block walks
+    // its share of them one after the other, a record per (column group, row lane)
+    for (int64_t sg = blockIdx.x; sg < nsuper; sg += gridDim.x) {
+        const int64_t cg = sg * kGramWaves + wave;
+        const int64_t a0 = cg * kCrossA;
+        const V* av[kCrossTA];
+        bool aact[kCrossTA];
+#pragma unroll
+        for (int grp = 0; grp < kCrossTA; ++grp) {
+            const int64_t col = a0 + 16 * grp + c;
+            aact[grp] = cg < ngroups && col < p;
+            av[grp] = reinterpret_cast<const V*>(X + (aact[grp] ? col : 0) * ld);
+        }
+        dvec4 tile[kCrossTA * kCrossTB];
+#pragma unroll
+        for (int t = 0; t < kCrossTA * kCrossTB; ++t) tile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
+        V breg[kCrossB / kGramWaves];
+        __syncthreads();                       // the previous super-group's last chunk has been consumed
+        if (nq > 0) { load_b(breg, 0); store_b(breg, 0); }
+        __syncthreads();
+        for (int64_t q = 0; q < nq; ++q) {
+            const int buf = (int)(q & 1);
+            const int64_t v0 = chunk_v0(q);
+            if (q + 1 < nq) load_b(breg, q + 1);          // in flight while this chunk is multiplied
+            if (v0 < nvec) {
 #pragma unroll 1
-            for (int u0 = 0; u0 < 16; u0 += kCrossUH) {
-                V xa[kCrossUH][kCrossTA], xb[kCrossUH][kCrossTB];
+                for (int u0 = 0; u0 < 16; u0 += kCrossUH) {
+                    V xa[kCrossUH][kCrossTA], xb[kCrossUH][kCrossTB];
 #pragma unroll
-                for (int u = 0; u < kCrossUH; ++u) {
-                    const int64_t v = v0 + 4 * (u0 + u) + g;
-                    const bool in = v < nvec;
+                    for (int u = 0; u < kCrossUH; ++u) {
+                        const int64_t v = v0 + 4 * (u0 + u) + g;
+                        const bool in = v < nvec;
 #pragma unroll
-                    for (int grp = 0; grp < kCrossTB; ++grp)   // shared by every column group: let the caches keep it
-                        xb[u][grp] = (bact[grp] && in) ? ld_stream<false>(bv[grp] + v) : vzero((V*)nullptr);
+                        for (int grp = 0; grp < kCrossTA; ++grp)
+                            xa[u][grp] = (aact[grp] && in) ? ld_stream<true>(av[grp] + v) : vzero((V*)nullptr);
 #pragma unroll
-                    for (int grp = 0; grp < kCrossTA; ++grp)
-                        xa[u][grp] = (aact[grp] && in) ? ld_stream<true>(av[grp] + v) : vzero((V*)nullptr);
-                }
-#pragma unroll
-                for (int u = 0; u < kCrossUH; ++u)
-#pragma unroll
-                    for (int e = 0; e < NV; ++e) {
-                        double b[kCrossTB];
-#pragma unroll
-                        for (int gb = 0; gb < kCrossTB; ++gb) b[gb] = (double)xb[u][gb][e];
-#pragma unroll
-                        for (int ga = 0; ga < kCrossTA; ++ga) {
-                            const double a = (double)xa[u][ga][e];
-#pragma unroll
-                            for (int gb = 0; gb < kCrossTB; ++gb)
-                                tile[ga * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[gb], tile[ga * kCrossTB + gb], 0, 0, 0);
-                        }
+                        for (int grp = 0; grp < kCrossTB; ++grp) xb[u][grp] = s_b[buf][(16 * grp + c) * kCrossXS + 4 * (u0 + u) + g];
                     }
+#pragma unroll
+                    for (int u = 0; u < kCrossUH; ++u)
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) {
+                            double b[kCrossTB];
+#pragma unroll
+                            for (int gb = 0; gb < kCrossTB; ++gb) b[gb] = (double)xb[u][gb][e];
+#pragma unroll
+                            for (int ga = 0; ga < kCrossTA; ++ga) {
+                                const double a = (double)xa[u][ga][e];
+#pragma unroll
+                                for (int gb = 0; gb < kCrossTB; ++gb)
+                                    tile[ga * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[gb], tile[ga * kCrossTB + gb], 0, 0, 0);
+                            }
+                        }
+                }
             }
+            if (q + 1 < nq) store_b(breg, buf ^ 1);
+            __syncthreads();                   // the next chunk is in LDS; this one has been read by every wave
+        }
+        // this wave's record: its own column group (waves past the last group have nothing to write)
+#pragma unroll
+        for (int t = 0; t < kCrossTA * kCrossTB; ++t) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) s_red[wave][(g + 4 * q4) * 16 + c] = tile[t][q4];   // D[i = g + 4 q4][j = c]
+            __builtin_amdgcn_wave_barrier();
+            if (cg < ngroups) {
+                double* __restrict__ out = partials + (cg * gridDim.y + blockIdx.y) * kCrossRec + t * 256;
+#pragma unroll
+                for (int v = lane; v < 256; v += 64) out[v] = s_red[wave][v];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    double* __restrict__ out = partials + (cg * gridDim.y + blockIdx.y) * kCrossRec;
-#pragma unroll
-    for (int t = 0; t < kCrossTA * kCrossTB; ++t) {
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) s_red[wave][(g + 4 * q4) * 16 + c] = tile[t][q4];   // D[i = g + 4 q4][j = c]
-        __syncthreads();
-        {
-            const int v = threadIdx.x;
-            double sum = 0.0;
-#pragma unroll
-            for (int wv = 0; wv < kGramWaves; ++wv) sum += s_red[wv][v];
-            out[t * 256 + v] = sum;
-        }
-        __syncthreads();
-    }
-    }   // cg
 }
 // out[cg][v] = sum over the J row-slab records of column group cg, in a fixed order
 __global__ __launch_bounds__(256) void k_cross_reduce(const double* __restrict__ partials, int J, double* __restrict__ out) {
