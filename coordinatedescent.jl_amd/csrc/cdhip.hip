@@ -319,8 +319,10 @@ int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
 }
 
 // ---- r catches up with the covariance-form visits: r -= sum_k pending_k X_k, 64 columns per launch ----------
-// Called by everything that reads r (the streaming kernels, the dots, the moments, the download) and by the
-// entry points that may have run covariance-form chunks, so outside the library r is always y - X beta.
+// Called by everything that reads r -- the streaming kernels, the dots, the moments, the Gram entry point, the
+// download (cdh_get_residual) -- and before X itself changes; nothing else needs r, so a warm-started path
+// whose solves all run from the cache pays for one catch-up when its caller finally asks for the residual
+// (moves of the same coordinate merge in the meantime).
 int32_t sync_r(cdh_handle h) {
     if (h->r_pending_list.empty()) return CDH_OK;
     std::vector<int64_t>& L = h->r_pending_list;
@@ -1293,7 +1295,6 @@ static int32_t cdh_pass_impl(cdh_handle h, int64_t m, const int64_t* idx1, doubl
     double maxH = 0.0;
     if (m > 0) CHK(run_pass(h, idx0.data(), m, &maxH, h->screening >= 2));
     else h->x.dropzeros();
-    CHK(sync_r(h));                    // on return r is y - X beta again, whatever form the visits took
     if (out_maxH) *out_maxH = maxH;
     return CDH_OK;
 }
@@ -1304,7 +1305,6 @@ static int32_t cdh_solve_impl(cdh_handle h, const cdh_options* opt, cdh_stats* o
     cdh_stats st{};
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
     int32_t rc = solve(h, opt, sched, &st);
-    if (rc == CDH_OK) rc = sync_r(h);
     if (out) *out = st;
     return rc;
 }
@@ -1348,7 +1348,6 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
             HIPCHK(h, hipStreamSynchronize(h->stream));
         }
     }
-    if (rc == CDH_OK) rc = sync_r(h);
     if (out) *out = st;
     return rc;
 }

@@ -208,7 +208,7 @@ int32_t cdh_set_screening(cdh_handle h, int32_t on);
  * While the cache is engaged the visits themselves need no read of X either (least squares, sqrt-lasso): the block
  * record the scalar-update kernel consumes -- X_k'r, the Gram entries between the block's coordinates -- is
  * read off the cached gradient and Gram columns ("covariance form"), and r is brought up to date once, before
- * anything reads it and before any entry point returns.
+ * anything reads it (cdh_get_residual, the moments, a streamed visit, ...).
  * cdh_cache_stats: out9 = {passes served, visits settled from the cache, visits made in those passes,
  * dots-only re-reference passes over X, Gram batches (up to 32 columns, at most 1.5 passes over X each),
  * Gram columns held, visits made in covariance form, residual catch-ups, covariance chunks rolled back
