@@ -202,15 +202,16 @@ int32_t cdh_set_screening(cdh_handle h, int32_t on);
  * times on one X.  mode: 0 off; 1 (default) engages once the handle has run as many screened full passes on
  * the same data as the Gram columns of its support cost to fetch (at least three; a cold start engages at
  * once); 2 from the first full pass (what a path driver that knows it has 100 lambdas to go asks for).
- * Modes 1 and 2 engage only while n_total >= 400 * nnz(x): folding a move into the cached gradient is p host
- * flops, which beats re-reading X only on tall problems; mode 3 is mode 2 without that guard (tests).
+ * Modes 1 and 2 engage only while n_total >= 400 * nnz(x): carrying a move through the host-side re-check of
+ * skipped certificates is p host flops, which beats re-reading X only on tall problems; mode 3 is mode 2
+ * without that guard (tests).
  * Same iterates, support order and pass counts as visiting every coordinate.
  * While the cache is engaged the visits themselves need no read of X either (least squares, sqrt-lasso): the block
  * record the scalar-update kernel consumes -- X_k'r, the Gram entries between the block's coordinates -- is
  * read off the cached gradient and Gram columns ("covariance form"), and r is brought up to date once, before
  * anything reads it (cdh_get_residual, the moments, a streamed visit, ...).
  * cdh_cache_stats: out9 = {passes served, visits settled from the cache, visits made in those passes,
- * dots-only re-reference passes over X, Gram batches (up to 32 columns, at most 1.5 passes over X each),
+ * dots-only re-reference passes over X, Gram batches (up to 32 columns, one pass over X each),
  * Gram columns held, visits made in covariance form, residual catch-ups, covariance chunks rolled back
  * because a skipped coordinate's certificate did not survive the chunk's own moves}. */
 int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode);
