@@ -104,7 +104,20 @@ def host_threads(omp_max):
             n = min(n, max(1, int(int(quota) / int(period))))
     except Exception:
         pass
-    return max(1, min(n, 16))  # a 1-GPU box gets a 16-CPU share
+    return max(1, n)
+
+
+def host_cpu_model():
+    """Model name of the box's CPU as /proc/cpuinfo gives it, and the logical CPUs the machine has in all."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return model, os.cpu_count()
 
 
 def cpu_baseline(f, n, lam, visits_target_s=12.0):
@@ -120,6 +133,7 @@ def cpu_baseline(f, n, lam, visits_target_s=12.0):
     y = f.y.astype(np.float64, copy=False)
     out = {}
     beta_cpu = None
+    cpu_model, machine_cpus = host_cpu_model()
     for threads in (1, host_threads(int(L.cdo_max_threads()))):
         r = y.copy()
         beta = np.zeros(ncol)
@@ -132,6 +146,8 @@ def cpu_baseline(f, n, lam, visits_target_s=12.0):
         L.cdo_bench_ls_visits(n, ncol, O._ptr(X), n, O._ptr(r), O._ptr(beta), lam, visits, threads)
         dt = time.perf_counter() - t0
         out[threads] = dict(value=visits / dt, unit="coord-updates/s", cores=threads, kind="port",
+                            cpu_model=cpu_model, machine_logical_cpus=machine_cpus,
+                            threads_allowed=len(os.sched_getaffinity(0)),
                             sample=f"{visits} visits cycling a {ncol}-column slice of the same X, n={n}, fp64; "
                                    f"{dt / visits * 1e3:.2f} ms/visit; p-sweep extrapolated x(p/visits)")
         if threads == 1:
@@ -268,6 +284,38 @@ def adopt_direct_exchange(mode, selftest_ok, all_ranks_completed, max_abs_dbeta,
                 and 0.0 < t_direct < t_rccl)
 
 
+def launcher_command(argv, gpus, port):
+    """The command the parent of a launcher-less `bench.py --gpus N` starts: torch.distributed.run with one
+    rank per GPU on this node, this very script and the caller's own arguments behind it."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): this process becomes the
+    launcher's parent.  It never touches the GPU -- no HIP call, no import of the library -- starts the N ranks
+    as a CHILD process (never an exec), relays rank 0's single JSON line on stdout, everything else on stderr,
+    and exits with the child's return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    child = subprocess.Popen(launcher_command(argv, gpus, port), env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for line in child.stdout:
+        s = line.strip()
+        if s.startswith("{") and '"metric"' in s:
+            lines.append(s)
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    for s in lines[-1:]:
+        print(s, flush=True)
+    return rc if rc != 0 or lines else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,19 +349,27 @@ def main():
                     help="do not measure roofline.traffic with rocprofv3 --pmc child runs (the committed figure is used)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], a.gpus))     # before anything below initialises HIP
+
     import numpy as np
     import coordinatedescent_jl_amd as cd
     from importlib import import_module
     sharded = import_module("coordinatedescent_jl_amd.sharded")
 
     cp = sharded.ControlPlane()
-    assert cp.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={cp.world}"
+    if cp.world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={cp.world} ranks "
+                 f"(run `python bench.py --gpus N` without a launcher, or make the two agree)")
     row0, n_local = sharded.shard_rows(a.rows, cp.rank, cp.world)
     dtype = np.float64 if a.dtype == "f64" else np.float32
     L = cd._lib.lib()
     ndev = cd._lib.C.c_int32()
     L.cdh_device_count(cd._lib.C.byref(ndev))
     device = cp.local_rank % max(ndev.value, 1)
+    import struct
+    # which card every rank drives, in rank order (one rank per GPU unless the box has fewer cards than ranks)
+    devices = list(struct.unpack(f"<{cp.world}q", cp.all_gather_bytes(struct.pack("<q", device))))
 
     f, bstar = cd.CDLeastSquaresLoss.generate(n_local, a.cols, seed=123, s=a.planted, noise=a.noise, dtype=dtype,
                                               device=device, n_total=a.rows, row_offset=row0)
@@ -426,7 +482,7 @@ def main():
         st = f.exchange_stats()
         return {
             "metric": "coord_updates_per_sec", "value": updates / dt, "unit": "coord-updates/s",
-            "n_gpus": cp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "n_gpus": cp.world, "devices_by_rank": devices, "visible_devices": ndev.value, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic",
             "config": {"workload": f"lasso_full_cyclic_sweep_gaussian_n{a.rows}_p{a.cols}_{a.dtype}_allmove",

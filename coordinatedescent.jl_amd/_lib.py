@@ -135,6 +135,8 @@ def lib():
         "cdh_set_use_graph": [vp, i32],
         "cdh_set_gradient_cache": [vp, i32],
         "cdh_cache_stats": [vp, P(i64)],
+        "cdh_get_gradient_cache": [vp, P(i32)],
+        "cdh_cache_drift": [vp, i32, P(f64)],
         "cdh_set_screening": [vp, i32],
         "cdh_comm_unique_id": [vp],
         "cdh_comm_init": [vp, vp, i32, i32],

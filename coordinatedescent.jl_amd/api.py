@@ -291,6 +291,18 @@ class _HipLoss(CoordinateDifferentiableFunction):
         """0 off, 1 rent-or-buy (default), 2 from the first full pass, 3 = 2 without the tall-problem guard."""
         check(self._L.cdh_set_gradient_cache(self._h, int(mode)), self._h)
 
+    def gradient_cache_mode(self):
+        out = C.c_int32()
+        check(self._L.cdh_get_gradient_cache(self._h, C.byref(out)), self._h)
+        return out.value
+
+    def cache_drift(self, rereference_now=False):
+        """max_k |g_carried - X_k'r| / thr_k at the gradient cache's re-references (cdh_cache_drift); with
+        rereference_now the carried gradient is taken afresh from X first (one dots-only pass) and measured."""
+        out = (C.c_double * 3)()
+        check(self._L.cdh_cache_drift(self._h, int(bool(rereference_now)), out), self._h)
+        return {"last": out[0], "max": out[1], "measured": int(out[2])}
+
     def cache_stats(self):
         out = (C.c_int64 * 9)()
         check(self._L.cdh_cache_stats(self._h, out), self._h)
@@ -679,8 +691,11 @@ def LassoPath(X, Y, lambdapath, options=None, max_hat_s=np.inf, standardizeX=Tru
     # x and f are shared by all lambdas; after the first solve the carried residual already
     # equals y - X x, so later warm starts skip the redundant initialize! (rounding-level effect)
     check(f._L.cdh_set_reuse_residual(f._h, 1 if reuse_residual else 0), f._h)
-    # a path is many solves on one X: the gradient cache need not wait for evidence of that (mode 2)
-    check(f._L.cdh_set_gradient_cache(f._h, 2), f._h)
+    # a path is many solves on one X: the gradient cache need not wait for evidence of that (1 -> 2 for the
+    # duration of the path).  Whatever else the caller -- or CDH_GRADIENT_CACHE -- set on this loss stays: 0 is off.
+    mode_before = f.gradient_cache_mode()
+    if mode_before == 1:
+        check(f._L.cdh_set_gradient_cache(f._h, 2), f._h)
     try:
         for i, lam in enumerate(lambdapath):
             coordinateDescent_(x, f, ProxL1(lam, sx), options)
@@ -690,5 +705,6 @@ def LassoPath(X, Y, lambdapath, options=None, max_hat_s=np.inf, standardizeX=Tru
                 break
     finally:
         check(f._L.cdh_set_reuse_residual(f._h, 0), f._h)
-        check(f._L.cdh_set_gradient_cache(f._h, 1), f._h)
+        if mode_before == 1:
+            check(f._L.cdh_set_gradient_cache(f._h, 1), f._h)
     return LassoPathResult(lambdapath, betapath)

@@ -109,6 +109,8 @@ struct GradCache {
     double q = 0.0;                 // r'r of the (virtual) residual g describes: sqrt-lasso thresholds and updates
     bool q_valid = false;
     int64_t n_rollbacks = 0;
+    double drift_last = 0.0, drift_max = 0.0;   // max_k |g_carried - X'r| / thr_k at the re-references so far
+    int64_t n_drift = 0;
     int64_t n_validate = 0, n_batches = 0, n_columns = 0, n_certified = 0, n_exact = 0, n_passes = 0, n_cov = 0,
             n_reconcile = 0;
 };
@@ -168,6 +170,7 @@ struct cdh_handle_s {
     unsigned p2p_epoch = 0, p2p_spin_limit = cdk::kP2PSpinLimit;
     int p2p_ranks = 0;
     bool p2p_on = false, p2p_dead = false;
+    bool lost_exchange = false;       // a multi-rank shard whose host transport was taken away: allreduce() refuses
     unsigned* d_p2p_base = nullptr;   // epoch base of a replayed graph's exchanges (device memory)
     bool capturing = false;           // run_chunk is recording a graph: exchanges take base + offset epochs
     unsigned cap_exchanges = 0, cap_rccl = 0;   // exchanges recorded in the graph being captured
@@ -247,7 +250,9 @@ int32_t upload_ctrl(cdh_handle h) {
 
 // p2p_dead counts: a shard that lost its exchange must never fall into the single-process (fused)
 // finalize kernels on its local rows -- every path then reaches allreduce(), which refuses
-inline bool sharded(const cdh_handle_s* h) { return h->comm != nullptr || h->p2p_on || h->p2p_dead || h->host_fn != nullptr; }
+inline bool sharded(const cdh_handle_s* h) {
+    return h->comm != nullptr || h->p2p_on || h->p2p_dead || h->lost_exchange || h->host_fn != nullptr;
+}
 
 int32_t p2p_check(cdh_handle h) {
     // after a timeout the ranks no longer agree on what has been exchanged: the handle refuses every
@@ -265,6 +270,10 @@ static_assert(GramRec<4>::N <= cdk::kP2PMaxCount, "the widest block record must 
 // Epochs count direct exchanges; 0 means "never written".  Consecutive epochs must alternate the
 // inbox slot (parity), also across the 32-bit wrap.
 constexpr unsigned kEpochWrap = 0xfffffff0u;
+// Chunks start below this: every rank passes a chunk boundary with the same epoch count whether it replays a
+// graph or launches node by node, so wrapping THERE keeps ranks on different paths in step (a chunk issues far
+// fewer than 2^28 exchanges, so the hard wrap above is never reached inside one)
+constexpr unsigned kEpochSoftWrap = 0xf0000000u;
 inline unsigned epoch_after(unsigned e) { return e >= kEpochWrap ? ((e & 1u) ? 2u : 3u) : e + 1u; }
 // the arguments of the next direct exchange.  While a graph is being recorded the epoch is
 // (device-resident base) + (position of the exchange in the graph), so one graph serves every replay.
@@ -307,6 +316,7 @@ int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
         return CDH_OK;
     }
     if (h->p2p_dead) return fail(h, CDH_RCCL_ERROR, "the shard lost its exchange (p2p timed out earlier); rebuild the handle");
+    if (h->lost_exchange) return fail(h, CDH_RCCL_ERROR, "the shard's host exchange was removed and nothing replaced it: its sums would cover local rows only");
     if (!h->comm) return CDH_OK;
     int rc = g_rccl.AllReduce(dbuf, dbuf, count, kNcclDouble, kNcclSum, h->comm, h->stream);
     if (rc != 0) {
@@ -652,6 +662,7 @@ template <typename T> int32_t launch_coord_chunk(cdh_handle h, int m) {
 
 int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     CHK(sync_r(h));   // the streaming kernels read and write r
+    if (h->p2p_epoch >= kEpochSoftWrap) h->p2p_epoch = (h->p2p_epoch & 1u) ? 1u : 2u;   // slot parity keeps alternating
     std::memcpy(h->h_idx, idx0, sizeof(int64_t) * (size_t)m);
     note_duplicates(h, idx0, m);
     HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
@@ -712,7 +723,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
         if (entry) {
             if (entry->exchanges) {
                 // epochs base+1 .. base+exchanges; across the 32-bit wrap the slot parity keeps alternating
-                if (h->p2p_epoch + entry->exchanges >= kEpochWrap) h->p2p_epoch = (h->p2p_epoch & 1u) ? 1u : 2u;
+                if ((uint64_t)h->p2p_epoch + entry->exchanges >= (uint64_t)kEpochWrap) h->p2p_epoch = (h->p2p_epoch & 1u) ? 1u : 2u;
                 hipLaunchKernelGGL(cdk::k_set_u32, dim3(1), dim3(1), 0, h->stream, h->d_p2p_base, h->p2p_epoch);
                 h->p2p_epoch += entry->exchanges;
                 h->n_p2p_calls += entry->exchanges;
@@ -1498,6 +1509,24 @@ int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode) {
     return CDH_OK;
 }
 
+int32_t cdh_get_gradient_cache(cdh_handle h, int32_t* out_mode) {
+    NEED_H(h);
+    NEED_P(h, out_mode);
+    *out_mode = h->gc.mode;
+    return CDH_OK;
+}
+
+static int32_t cdh_cache_drift_impl(cdh_handle h, int32_t rereference_now, double* out3) {
+    NEED_P(h, out3);
+    GradCache& c = h->gc;
+    if (rereference_now && c.valid && gc_applicable(h)) {
+        HIPCHK(h, hipSetDevice(h->device));
+        CHK(gc_rereference(h));
+    }
+    out3[0] = c.drift_last; out3[1] = c.drift_max; out3[2] = (double)c.n_drift;
+    return CDH_OK;
+}
+
 int32_t cdh_cache_stats(cdh_handle h, int64_t* out9) {
     NEED_H(h);
     NEED_P(h, out9);
@@ -1610,7 +1639,12 @@ int32_t cdh_p2p_enable(cdh_handle h, int32_t on) {
 
 int32_t cdh_set_host_exchange(cdh_handle h, cdh_host_allreduce_fn fn, void* user, int32_t rank, int32_t nranks) {
     NEED_H(h);
-    if (!fn) { h->host_fn = nullptr; h->host_user = nullptr; return CDH_OK; }
+    if (!fn) {
+        // a shard of a multi-rank problem must not quietly fall into the single-process kernels on its local rows
+        if (h->host_fn && h->nranks > 1 && !h->comm && !h->p2p_ranks) h->lost_exchange = true;
+        h->host_fn = nullptr; h->host_user = nullptr;
+        return CDH_OK;
+    }
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, CDH_BAD_ARG, "bad rank / nranks");
     if (h->comm || h->p2p_ranks) return fail(h, CDH_BAD_ARG, "the handle already has an exchange (RCCL / direct)");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1619,6 +1653,7 @@ int32_t cdh_set_host_exchange(cdh_handle h, cdh_host_allreduce_fn fn, void* user
         HIPCHK(h, hipHostMalloc((void**)&h->h_xchg, sizeof(double) * h->h_xchg_doubles));
     }
     h->host_fn = fn; h->host_user = user; h->rank = rank; h->nranks = nranks;
+    h->lost_exchange = false;
     return CDH_OK;
 }
 
@@ -1770,6 +1805,12 @@ int32_t cdh_gradient(cdh_handle h, int64_t k1, double* out) {
 int32_t cdh_descend(cdh_handle h, int64_t k1, double* out_h) {
     NEED_H(h);
     try { return cdh_descend_impl(h, k1, out_h); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_cache_drift(cdh_handle h, int32_t rereference_now, double* out3) {
+    NEED_H(h);
+    try { return cdh_cache_drift_impl(h, rereference_now, out3); }
     CDH_CATCH(h)
 }
 

@@ -46,12 +46,17 @@ int32_t gc_size(cdh_handle h) {   // first use on this handle
     const int64_t nsuper = (launches + kGramWaves - 1) / kGramWaves;   // a block's four waves take four column groups
     c.cross_GX = (int)std::max<int64_t>(1, std::min<int64_t>(nsuper, gxe ? atoi(gxe) : 4));
     c.cross_J = (int)std::max<int64_t>(1, std::min<int64_t>(nslabs, (2 * (int64_t)h->cus) / c.cross_GX));
+    // (a handle whose first sizing failed may be asked again: what a failed attempt got was freed below)
     bool fits = hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec) == hipSuccess &&
                 hipMalloc((void**)&c.d_cross_part, sizeof(double) * (size_t)launches * (size_t)c.cross_J * kCrossRec) == hipSuccess &&
                 hipMalloc((void**)&c.d_cols, sizeof(int64_t) * kCrossB) == hipSuccess;
     if (!fits) (void)hipGetLastError();
     CHK(all_ranks_agree(h, fits, &fits));
     if (!fits) {                      // no room for the cache's scratch (on some rank): the dots-only screens stay
+        if (c.d_cross) (void)hipFree(c.d_cross);
+        if (c.d_cross_part) (void)hipFree(c.d_cross_part);
+        if (c.d_cols) (void)hipFree(c.d_cols);
+        c.d_cross = nullptr; c.d_cross_part = nullptr; c.d_cols = nullptr;
         c.mode = 0;
         c.g.clear(); c.g.shrink_to_fit();
         return CDH_OK;
@@ -126,9 +131,14 @@ int32_t gc_ensure_q(cdh_handle h) {
 }
 
 // fold what can be folded, then ask cov_ok (the active passes of a solve call this before every chunk)
+int32_t gc_rereference(cdh_handle h);
 bool gc_ready_for_cov(cdh_handle h, const int64_t* idx0, int64_t m) {
     GradCache& c = h->gc;
     if (!c.cov || !c.valid || !gc_applicable(h) || !c.d_G) return false;
+    // the same bounds the full passes keep (gc_full_pass): the cache only pays on tall problems, and g is carried
+    // through a bounded number of covariance-form updates before it is taken afresh from X
+    if (c.mode != 3 && h->x.nnz() * kGcRowsPerNnz > h->n_total) { gc_invalidate(h, false); return false; }
+    if (c.cov_since_ref > c.refresh_after && gc_rereference(h) != CDH_OK) return false;
     if (!c.moved.empty()) {
         for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return false;
         gc_fold(h);
@@ -242,6 +252,41 @@ int32_t gc_validate(cdh_handle h) {
     return CDH_OK;
 }
 
+// Take g afresh from X (one dots-only pass) and MEASURE how far the carried g had drifted from it:
+//   drift = max_k |g_carried[k] - X_k'r| / thr_k   (thr_k: the threshold the certificates compare |g_k| with)
+// -- the quantity the certificates' relative margin must cover.  Pending moves are folded first so that both sides
+// describe the same residual; what is known about beta is kept (g will describe the same residual, freshly summed).
+int32_t gc_rereference(cdh_handle h) {
+    GradCache& c = h->gc;
+    const bool beta_known = c.beta_ok;
+    std::vector<double> beta_keep;
+    if (beta_known) beta_keep = c.beta_ref;
+    bool comparable = c.valid;
+    if (comparable)
+        for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) comparable = false;
+    std::vector<double> carried;
+    if (comparable) { gc_fold(h); carried = c.g; }
+    gc_invalidate(h, false);
+    CHK(gc_validate(h));
+    c.beta_ok = beta_known;
+    if (beta_known) c.beta_ref.swap(beta_keep);
+    if (comparable && h->ctrl.lambda0 > 0.0) {
+        double scale = h->ctrl.lambda0 * (double)h->n_total;
+        if (h->loss == CDH_SQRT) { CHK(gc_ensure_q(h)); scale = h->ctrl.lambda0 * std::sqrt(c.q); }
+        double worst = 0.0;
+        for (int64_t k = 0; k < h->p; ++k) {
+            const double thr = scale * (h->has_omega ? h->h_omega[(size_t)k] : 1.0);
+            if (!(c.a[(size_t)k] > 0.0) || !(thr > 0.0)) continue;
+            const double d = std::fabs(carried[(size_t)k] - c.g[(size_t)k]) / thr;
+            if (d > worst) worst = d;
+        }
+        c.drift_last = worst;
+        if (worst > c.drift_max) c.drift_max = worst;
+        c.n_drift += 1;
+    }
+    return CDH_OK;
+}
+
 // Gram columns G_j = X'X_j for the coordinates in `cols` (those not cached yet), up to 32 per pass over X
 int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
     GradCache& c = h->gc;
@@ -345,31 +390,25 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
         if (c.valid) gc_invalidate(h, false);
         return CDH_OK;
     }
-    if (h->x.nnz() > kGcMaxSupport) return CDH_OK;
+    // g has been carried through this many covariance-form updates without looking at X: it is taken afresh
+    // below (rounding only ever accumulates in g; one dots-only pass resets it), or dropped if this pass turns
+    // out to run the plain way -- the active passes that follow must not keep carrying it either
+    const bool refresh_due = c.valid && c.cov_since_ref > c.refresh_after;
+    if (h->x.nnz() > kGcMaxSupport) { if (refresh_due) gc_invalidate(h, false); return CDH_OK; }
     if (c.cooldown > 0) { c.cooldown -= 1; if (c.valid) gc_invalidate(h, false); return CDH_OK; }
     CHK(gc_size(h));
     if (c.mode == 0) return CDH_OK;
     const double lam = h->ctrl.lambda0, nt = (double)h->n_total;
     const std::vector<double>& om = h->h_omega;
     // 1. a current g: fold the pending moves, fetching the columns that are missing; too many missing (or no
-    //    reference yet): one dots-only pass over X gives a fresh g instead
-    // g has been carried through this many covariance-form updates without looking at X: take it afresh
-    // (rounding only ever accumulates in g; one dots-only pass resets it)
-    // (re-referencing keeps what is known about beta: g will describe the same residual, only freshly summed)
-    const bool beta_known = c.beta_ok;
-    std::vector<double> beta_keep;
-    if (beta_known) beta_keep = c.beta_ref;
-    if (c.valid && c.cov_since_ref > c.refresh_after) gc_invalidate(h, false);
+    //    reference yet, or the carried one is due): one dots-only pass over X gives a fresh g instead
+    //    (re-referencing keeps what is known about beta: g will describe the same residual, only freshly summed)
     std::vector<int64_t> want;
-    if (c.valid) {
+    if (c.valid && !refresh_due) {
         for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) want.push_back(j);
         if ((int)want.size() > kGcMaxFetch) { gc_invalidate(h, false); want.clear(); }
     }
-    if (!c.valid) {
-        CHK(gc_validate(h));
-        c.beta_ok = beta_known;
-        if (beta_known) c.beta_ref.swap(beta_keep);
-    }
+    if (!c.valid || refresh_due) CHK(gc_rereference(h));
     for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_)       // the support moves in every pass: its columns first
         if (c.slot[(size_t)h->x.coord(s_)] < 0) want.push_back(h->x.coord(s_));
     double rnorm = 0.0;

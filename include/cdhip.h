@@ -215,7 +215,16 @@ int32_t cdh_set_screening(cdh_handle h, int32_t on);
  * Gram columns held, visits made in covariance form, residual catch-ups, covariance chunks rolled back
  * because a skipped coordinate's certificate did not survive the chunk's own moves}. */
 int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode);
+/* The mode the handle is in now (a path driver upgrades 1 -> 2 for its own duration and puts back what it found:
+ * lasso.jl:250-252 runs on a caller's loss object, whose settings are the caller's). */
+int32_t cdh_get_gradient_cache(cdh_handle h, int32_t *out_mode);
 int32_t cdh_cache_stats(cdh_handle h, int64_t *out9);
+/* How far the carried gradient has been from X'r whenever it was taken afresh from X (after CDH_GC_REFRESH
+ * covariance-form visits, or right now with rereference_now != 0: one dots-only pass over X):
+ *   drift = max_k |g_carried[k] - X_k'r| / thr_k,   thr_k = lambda0 n omega_k (sqrt-lasso: lambda0 omega_k ||r||)
+ * -- the quantity the certificates' relative margin (1e-9 for fp64 storage) has to cover.
+ * out3 = {drift at the last re-reference, the largest seen on this handle, re-references measured}. */
+int32_t cdh_cache_drift(cdh_handle h, int32_t rereference_now, double *out3);
 /* Replay each pass from a captured hipGraph instead of individual launches (the north_star's
  * "full sweep captured under hipGraph").  Works on row shards too: the direct exchange takes its epoch
  * from device memory, RCCL all-reduces are captured with the kernels around them; only the host-staged

@@ -15,9 +15,14 @@
 #   lasso(X, y, λ[, ω])        :26-53     coordinateDescent!
 #   sqrtLasso(X, y, λ, ω)      :84-98     coordinateDescent!      (standardizeX=true is dead code in the
 #   sqrtLasso(...; standardizeX=false)                             reference itself: `Array{T}(p)`, :73)
-#   scaledLasso!(x, X, y, λ, ω) :107-144  _findInitResiduals! (:Screening), initialize! (:WarmStart),
-#                                         coordinateDescent! per σ iteration
-#   LassoPath(X, Y, λpath)     :229-260   _stdX!, coordinateDescent! per λ
+#   scaledLasso!(x, X, y, λ, ω) :107-144  scaledLasso!(x, X::HipMatrix, ...) below: same loop, σ from the device
+#                                         (cdh_resid_moments), the residual copied back ONCE at the end
+#   LassoPath(X, Y, λpath)     :229-260   LassoPath(X::HipMatrix, ...) below: same loop, nothing n-sized moves
+#                                         between the λ (carried residual reused, gradient cache from the start)
+# The generic front-ends still work on a HipMatrix through the operator methods (_findInitResiduals!,
+# initialize!, coordinateDescent!, _stdX!), at the price of one n-sized device -> host copy per solve because
+# their bodies read `f.r` on the host (lasso.jl:134); the two methods above exist to take that copy out of
+# the σ loop and the λ loop.
 module CoordinateDescentHIP
 
 using CoordinateDescent, ProximalBase
@@ -26,7 +31,8 @@ using SparseArrays: nnz
 using DataStructures: nlargest
 import CoordinateDescent: coordinateDescent!, initialize!, gradient, descendCoordinate!,
                           numCoordinates, CDOptions, CDLeastSquaresLoss, CDSqrtLassoLoss, CDWeightedLSLoss,
-                          _stdX!, _findInitResiduals!, _findLargestCorrelations
+                          _stdX!, _findInitResiduals!, _findLargestCorrelations,
+                          scaledLasso!, LassoPath, LassoSolution, IterLassoOptions
 
 const libcdhip = get(ENV, "LIBCDHIP", "libcdhip.so")
 
@@ -60,14 +66,18 @@ end
 
 # A matrix whose columns live in HBM behind a cdh handle.  <: DenseMatrix so it satisfies
 # lasso(X::StridedMatrix{T}, ...) (src/lasso.jl:27); getindex is for display only.  The handle also
-# holds y, r (and w) of whichever loss object used it last: `owner` is the objectid of that loss's
-# residual vector (`f.r`, a fresh `copy(y)` per loss object, cd_differentiable_function.jl:54), so
-# every method below can tell whether the device-side y / loss kind are still its own.
+# holds y, r (and w) of whichever loss object used it last: `owner` IS that loss's residual vector
+# (`f.r`, a fresh `copy(y)` per loss object, cd_differentiable_function.jl:54), held by reference and
+# compared with `===`, so every method below can tell whether the device-side y / loss kind are still
+# its own.  (A strong reference, not an objectid: the id of a Vector is its address, and the next
+# `copy(y)` of the same length can land on the address of a collected one -- the handle would then
+# solve against the previous y.  Holding the vector keeps it alive and unaliased; the cost is n
+# elements of host memory per matrix until the next loss binds.)
 mutable struct HipMatrix{T<:Union{Float32,Float64}} <: DenseMatrix{T}
   handle::Ptr{Cvoid}
   n::Int
   p::Int
-  owner::UInt
+  owner::Any
 end
 Base.size(X::HipMatrix) = (X.n, X.p)
 Base.getindex(X::HipMatrix{T}, i::Int, j::Int) where {T} = begin
@@ -90,7 +100,7 @@ function HipMatrix(X::StridedMatrix{T}; device::Integer=0) where {T}
   h = ref[]
   GC.@preserve X check(h, ccall((:cdh_set_X_cols, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64),
                                 h, 0, p, X, stride(X, 2)))
-  M = HipMatrix{T}(h, n, p, UInt(0))
+  M = HipMatrix{T}(h, n, p, nothing)
   finalizer(m -> ccall((:cdh_destroy, libcdhip), Int32, (Ptr{Cvoid},), m.handle), M)
   M
 end
@@ -126,7 +136,7 @@ CDSqrtLassoLoss never runs the least-squares update.  (y mutated in place under 
 the one thing this cannot see: call `rebind!(f)`.)"
 function bind!(f::HipLoss{T}) where {T}
   X = f.X
-  X.owner == objectid(f.r) && return f
+  X.owner === f.r && return f
   rebind!(f)
 end
 function rebind!(f::HipLoss{T}) where {T}
@@ -134,7 +144,7 @@ function rebind!(f::HipLoss{T}) where {T}
   set_loss!(X, loss_kind(f))
   upload_y!(X, f.y)                                   # also r = copy(y), as the loss constructors do
   f isa HipWLS && upload_w!(X, f.w)
-  X.owner = objectid(f.r)
+  X.owner = f.r
   f
 end
 
@@ -157,7 +167,8 @@ end
 pull_residual!(f::HipLoss) =
   check(f.X.handle, ccall((:cdh_get_residual, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), f.X.handle, f.r))
 
-function pull_iterate!(f::HipLoss{T}, x::SparseIterate{T}) where {T}
+"x <- the handle's iterate, support in the library's insertion order (p-sized; nothing n-sized moves)"
+function pull_support!(f::HipLoss{T}, x::SparseIterate{T}) where {T}
   p = f.X.p
   idx = Vector{Int64}(undef, p); nz = Ref{Int64}(0); beta = Vector{Float64}(undef, p)
   check(f.X.handle, ccall((:cdh_get_support, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ref{Int64}), f.X.handle, idx, nz))
@@ -166,6 +177,11 @@ function pull_iterate!(f::HipLoss{T}, x::SparseIterate{T}) where {T}
   for i in 1:nz[]                       # re-insert in the library's support order
     x[idx[i]] = T(beta[idx[i]])
   end
+  x
+end
+
+function pull_iterate!(f::HipLoss{T}, x::SparseIterate{T}) where {T}
+  pull_support!(f, x)
   pull_residual!(f)
   x
 end
@@ -199,7 +215,8 @@ function descendCoordinate!(f::HipLoss{T}, g::ProxL1{T}, x::SparseIterate{T}, k:
 end
 
 # ---- the performance path: one ccall per solve (src/coordinate_descent.jl:7-39) ---------------
-function coordinateDescent!(x::SparseIterate{T}, f::HipLoss{T}, g::ProxL1, options::CDOptions=CDOptions()) where {T}
+"coordinateDescent! up to the point where results leave the device: x is refreshed, f.r is NOT"
+function solve_resident!(x::SparseIterate{T}, f::HipLoss{T}, g::ProxL1, options::CDOptions) where {T}
   ProximalBase.numCoordinates(x) == numCoordinates(f) || throw(DimensionMismatch())
   bind!(f)
   set_penalty!(f, g)                  # checks length(g.λ) == p (coordinate_descent.jl:14-16)
@@ -209,7 +226,13 @@ function coordinateDescent!(x::SparseIterate{T}, f::HipLoss{T}, g::ProxL1, optio
                f.X.handle, opt, st)
   check(f.X.handle, code)
   st.domain_error != 0 && throw(DomainError(NaN, "sqrt-lasso update"))
-  pull_iterate!(f, x)
+  pull_support!(f, x)
+end
+
+function coordinateDescent!(x::SparseIterate{T}, f::HipLoss{T}, g::ProxL1, options::CDOptions=CDOptions()) where {T}
+  solve_resident!(x, f, g, options)
+  pull_residual!(f)                   # callers read f.r next (lasso.jl:37,52,81,97)
+  x
 end
 
 # ---- the dense helpers the front-ends call on X itself (src/utils.jl) ---------------------------
@@ -230,7 +253,7 @@ end
 function xt_y(X::HipMatrix{T}, y::AbstractVector{T}) where {T}
   set_loss!(X, CDH_LS)
   upload_y!(X, y)
-  X.owner = UInt(0)                    # whatever loss was bound has lost its y: it re-binds on its next call
+  X.owner = nothing                    # whatever loss was bound has lost its y: it re-binds on its next call
   check(X.handle, ccall((:cdh_initialize, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
                         X.handle, X.p, 0, C_NULL, C_NULL))
   out = Vector{Float64}(undef, X.p)
@@ -263,6 +286,96 @@ function _findInitResiduals!(X::HipMatrix{T}, y::AbstractVector{T}, s::Int, stor
 end
 # _findInitSigma!(X, y, s, storage) = std(_findInitResiduals!(X, y, s, storage)) (utils.jl:60-64) is
 # generic and lands in the method above.
+
+# ---- the σ loop and the λ loop with nothing n-sized crossing the bus (src/lasso.jl:107-144, 229-260) ------
+"sum r, sum r^2 of the device-side residual (all shards)"
+function resid_moments(X::HipMatrix)
+  s = Ref{Float64}(0); ss = Ref{Float64}(0)
+  check(X.handle, ccall((:cdh_resid_moments, libcdhip), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}), X.handle, s, ss))
+  s[], ss[]
+end
+"std(f.r): mean-removed, Bessel-corrected (Statistics.std), from the two moments"
+function resid_std(X::HipMatrix)
+  s, ss = resid_moments(X)
+  sqrt(max(ss - s * s / X.n, 0.0) / (X.n - 1))
+end
+
+function gradient_cache_mode(X::HipMatrix)
+  m = Ref{Int32}(0)
+  check(X.handle, ccall((:cdh_get_gradient_cache, libcdhip), Int32, (Ptr{Cvoid}, Ref{Int32}), X.handle, m))
+  m[]
+end
+
+"scaledLasso!(x, X, y, λ, ω, options) (lasso.jl:107-144) for a design in HBM: the reference's loop with σ taken
+from the device-side residual; `f.r` comes back to the host once, for the LassoSolution."
+function scaledLasso!(x::SparseIterate{T}, X::HipMatrix{T}, y::AbstractVector{T}, λ::T, ω::AbstractVector{T},
+                      options::IterLassoOptions=IterLassoOptions()) where {T<:AbstractFloat}
+  n = X.n
+  f = CDLeastSquaresLoss(y, X)
+  if options.initProcedure == :Screening
+    # _findInitSigma! (utils.jl:60-64) without its copy back: scores, s x s normal equations, residual on the device
+    S = _findLargestCorrelations(X, y, options.sinit)      # leaves y on the device, loss kind LS, r = y
+    idx = Int64.(findall(S)); m = length(idx)
+    m <= 64 || throw(ArgumentError("screening set larger than 64 columns"))
+    G = Matrix{Float64}(undef, m, m); c = Vector{Float64}(undef, m)
+    check(X.handle, ccall((:cdh_gram, libcdhip), Int32,
+                          (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                          X.handle, m, idx, G, c, C_NULL))
+    coef = Symmetric(G) \ c
+    check(X.handle, ccall((:cdh_initialize, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
+                          X.handle, X.p, m, idx, coef))
+    σ = T(resid_std(X))
+    X.owner = f.r                     # the device holds exactly this loss's y and kind: no second upload
+  elseif options.initProcedure == :InitStd
+    σ = options.σinit
+  elseif options.initProcedure == :WarmStart
+    bind!(f); push_iterate!(f, x, true)
+    σ = T(resid_std(X))
+  else
+    throw(ArgumentError("Incorrect initialization Symbol"))
+  end
+  g = ProxL1(λ * σ, ω)
+  for iter = 1:options.maxIter
+    solve_resident!(x, f, g, options.optionsCD)
+    σnew = T(sqrt(resid_moments(X)[2] / n))                # sqrt(sum(abs2, f.r) / n), lasso.jl:134
+    abs(σnew - σ) / σ < options.optTol && break
+    σ = σnew
+    g = ProxL1(λ * σ, ω)
+  end
+  pull_residual!(f)
+  LassoSolution{T, typeof(g)}(x, f.r, g, T(resid_std(X)))
+end
+
+"LassoPath(X, Y, λpath, options; max_hat_s, standardizeX) (lasso.jl:229-260) for a design in HBM: one x and one f
+for all λ as in the reference; warm starts keep the carried residual (it already equals Y - X x) and the gradient
+cache is engaged from the first full pass for the duration of the path (whatever the caller set otherwise stays)."
+function LassoPath(X::HipMatrix{T}, Y::StridedVector{T}, λpath::Vector{T}, options=CDOptions();
+                   max_hat_s=Inf, standardizeX::Bool=true) where {T<:AbstractFloat}
+  p = X.p
+  stdX = Array{T}(undef, p)
+  standardizeX ? _stdX!(stdX, X) : fill!(stdX, one(T))
+  x = SparseIterate(T, p)
+  f = CDLeastSquaresLoss(Y, X)
+  numλ = length(λpath)
+  βpath = Vector{SparseIterate{T}}(undef, numλ)
+  mode_before = gradient_cache_mode(X)
+  set_reuse_residual!(X, true)
+  mode_before == 1 && set_gradient_cache!(X, 2)
+  try
+    for indλ = 1:numλ
+      solve_resident!(x, f, ProxL1(λpath[indλ], stdX), options)
+      βpath[indλ] = copy(x)
+      if nnz(x) > max_hat_s
+        resize!(λpath, indλ)
+        break
+      end
+    end
+  finally
+    set_reuse_residual!(X, false)
+    mode_before == 1 && set_gradient_cache!(X, 1)
+  end
+  LassoPath{T}(copy(λpath), βpath)
+end
 
 # Optional knobs (no reference counterpart): blocked sweep width, screened full passes, the gradient
 # cache of repeated solves, hipGraph replay, reuse of the carried residual by warm starts (what LassoPath

@@ -107,6 +107,15 @@ def main():
     np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-9)
     assert same_on_all_ranks(x.dense())
     cp.barrier()
+    # taking the transport away from a shard of a multi-rank problem must not leave it sweeping its local rows
+    # as if they were the whole problem: every later exchange refuses
+    f.set_host_exchange(None, 0, 1)
+    try:
+        cd.coordinateDescent_(x, f, cd.ProxL1(0.08, om), cd.CDOptions(**o))
+        raise AssertionError("a shard without its exchange kept sweeping")
+    except cd.HipError as e:
+        assert "exchange" in str(e)
+    cp.barrier()
     f.close()
     if cp.rank == 0:
         print("HOSTX_OK")

@@ -8,7 +8,8 @@ scaledLasso! (:Screening and :WarmStart), LassoPath (standardizeX) and CDWeighte
 cases round 1's binding got wrong (a second y on the same matrix, a sqrt-lasso loss on a handle
 created for least squares, two live loss objects on one matrix).
 
-Each replayed method names the binding function it mirrors; keep the two in step.
+Each replayed method names the binding function it mirrors.  That the .jl's ccall signatures and structs agree
+with include/cdhip.h is checked mechanically by tests/test_julia_binding_static.py (CPU).
 """
 import ctypes as C
 import os
@@ -90,7 +91,7 @@ class HipMatrix:
         assert st == 0, lib().cdh_last_error(None)
         self.handle = h
         ccall("cdh_set_X_cols", h, i64(0), i64(self.p), ptr(X), i64(X.strides[1] // X.itemsize))
-        self.owner = 0
+        self.owner = None
 
     def close(self):
         lib().cdh_destroy(self.handle)
@@ -127,11 +128,11 @@ def rebind(f):                       # rebind!(f)
     if f.kind == CDH_WLS:
         ww = np.ascontiguousarray(f.w, dtype=X.dtype)
         ccall("cdh_set_obs_weights", X.handle, ptr(ww))
-    X.owner = id(f.r)                # objectid(f.r)
+    X.owner = f.r                    # a strong reference to the loss's residual vector, compared with ===
 
 
 def bind(f):                         # bind!(f)
-    if f.X.owner != id(f.r):
+    if f.X.owner is not f.r:
         rebind(f)
 
 
@@ -146,13 +147,18 @@ def pull_residual(f):                # pull_residual!(f)
     ccall("cdh_get_residual", f.X.handle, ptr(f.r))
 
 
-def pull_iterate(f, x):              # pull_iterate!(f, x)
+def pull_support(f, x):              # pull_support!(f, x)
     p = f.X.p
     idx, nz, beta = np.zeros(p, dtype=np.int64), i64(0), np.zeros(p)
     ccall("cdh_get_support", f.X.handle, ptr(idx), C.byref(nz))
     ccall("cdh_get_beta", f.X.handle, ptr(beta))
     x.idx = idx[: nz.value].tolist()
     x.val = [float(beta[k - 1]) for k in x.idx]
+    return x
+
+
+def pull_iterate(f, x):              # pull_iterate!(f, x)
+    pull_support(f, x)
     pull_residual(f)
     return x
 
@@ -168,7 +174,7 @@ def initialize(f, x):                # initialize!(f, x)
     pull_residual(f)
 
 
-def coordinateDescent(x, f, lam0, omega, opt):     # coordinateDescent!(x, f, g, options)
+def solve_resident(x, f, lam0, omega, opt):        # solve_resident!(x, f, g, options)
     if x.p != f.X.p:
         raise DimensionMismatch()
     bind(f)
@@ -179,8 +185,98 @@ def coordinateDescent(x, f, lam0, omega, opt):     # coordinateDescent!(x, f, g,
     st = CdhStats()
     ccall("cdh_coordinate_descent", f.X.handle, C.byref(o), C.byref(st))
     assert st.domain_error == 0
-    pull_iterate(f, x)
+    pull_support(f, x)
     return st
+
+
+def coordinateDescent(x, f, lam0, omega, opt):     # coordinateDescent!(x, f, g, options)
+    st = solve_resident(x, f, lam0, omega, opt)
+    pull_residual(f)
+    return st
+
+
+N_RESIDUAL_COPIES = [0]               # how many n-sized device -> host copies the replayed methods have made
+_pull_residual_plain = pull_residual
+
+
+def pull_residual(f):                # noqa: F811  (the same call, counted)
+    N_RESIDUAL_COPIES[0] += 1
+    _pull_residual_plain(f)
+
+
+def resid_moments(X):                # resid_moments(X)
+    s, ss = f64(0), f64(0)
+    ccall("cdh_resid_moments", X.handle, C.byref(s), C.byref(ss))
+    return s.value, ss.value
+
+
+def resid_std(X):                    # resid_std(X)
+    s, ss = resid_moments(X)
+    return float(np.sqrt(max(ss - s * s / X.n, 0.0) / (X.n - 1)))
+
+
+def gradient_cache_mode(X):          # gradient_cache_mode(X)
+    m = i32(0)
+    ccall("cdh_get_gradient_cache", X.handle, C.byref(m))
+    return m.value
+
+
+def scaledLasso_hip(x, X, y, lam, omega, init, sinit, sigmainit, maxIter, optTol, optCD):
+    """scaledLasso!(x, X::HipMatrix, y, λ, ω, options): the binding's own method (device-resident σ loop)."""
+    n = X.n
+    f = Loss(CDH_LS, y, X)
+    if init == "Screening":
+        S = findLargestCorrelations(X, y, sinit)
+        idx = np.ascontiguousarray(np.nonzero(S)[0] + 1, dtype=np.int64)
+        m = len(idx)
+        assert m <= 64
+        G, c = np.zeros((m, m)), np.zeros(m)
+        ccall("cdh_gram", X.handle, i64(m), ptr(idx), ptr(G), ptr(c), None)
+        coef = np.ascontiguousarray(np.linalg.solve(G, c))
+        ccall("cdh_initialize", X.handle, i64(X.p), i64(m), ptr(idx), ptr(coef))
+        sigma = resid_std(X)
+        X.owner = f.r
+    elif init == "InitStd":
+        sigma = sigmainit
+    else:
+        bind(f)
+        push_iterate(f, x, True)
+        sigma = resid_std(X)
+    lam0 = lam * sigma
+    for _ in range(maxIter):
+        solve_resident(x, f, lam0, omega, optCD)
+        sigmanew = float(np.sqrt(resid_moments(X)[1] / n))
+        if abs(sigmanew - sigma) / sigma < optTol:
+            break
+        sigma = sigmanew
+        lam0 = lam * sigma
+    pull_residual(f)
+    return x, f.r, resid_std(X)
+
+
+def LassoPath_hip(X, Y, lams, opt, standardizeX=True, max_hat_s=np.inf):
+    """LassoPath(X::HipMatrix, Y, λpath, options; max_hat_s, standardizeX): the binding's own method."""
+    sx = stdX(X) if standardizeX else np.ones(X.p, dtype=X.dtype)
+    x = SparseIterate(X.p)
+    f = Loss(CDH_LS, Y, X)
+    lams = list(lams)
+    path = []
+    mode_before = gradient_cache_mode(X)
+    ccall("cdh_set_reuse_residual", X.handle, i32(1))
+    if mode_before == 1:
+        ccall("cdh_set_gradient_cache", X.handle, i32(2))
+    try:
+        for i, lam in enumerate(lams):
+            solve_resident(x, f, lam, sx, opt)
+            path.append(x.dense())
+            if len(x.idx) > max_hat_s:
+                lams = lams[: i + 1]
+                break
+    finally:
+        ccall("cdh_set_reuse_residual", X.handle, i32(0))
+        if mode_before == 1:
+            ccall("cdh_set_gradient_cache", X.handle, i32(1))
+    return lams, path
 
 
 def stdX(X):                         # _stdX!(out, X::HipMatrix)
@@ -193,7 +289,7 @@ def xt_y(X, y):                      # xt_y(X, y)
     ccall("cdh_set_loss", X.handle, i32(CDH_LS))
     yy = np.ascontiguousarray(y, dtype=X.dtype)
     ccall("cdh_set_y", X.handle, ptr(yy))
-    X.owner = 0
+    X.owner = None
     ccall("cdh_initialize", X.handle, i64(X.p), i64(0), None, None)
     out = np.zeros(X.p)
     ccall("cdh_xt_r", X.handle, ptr(out))
@@ -398,4 +494,55 @@ def test_fp32_path_sequence():
     path = LassoPath(Xh, Y.astype(np.float32), [0.2, 0.05], dict(maxIter=500, optTol=1e-6, randomize=False))
     lo, bo = O.LassoPath(X, Y, [0.2, 0.05], O.CDOptions(maxIter=500, optTol=1e-10, randomize=False))
     np.testing.assert_allclose(path[1], bo[1], rtol=0, atol=2e-4)     # fp32 storage against the fp64 oracle
+    Xh.close()
+
+
+@pytest.mark.parametrize("init", ["Screening", "InitStd", "WarmStart"])
+def test_scaled_lasso_hipmatrix_method_keeps_the_sigma_loop_on_the_device(init):
+    """scaledLasso!(x, X::HipMatrix, ...) of the binding: same sigma, beta and residual as the reference's loop,
+    with ONE n-sized copy back (the LassoSolution's residuals) however many sigma iterations run."""
+    rng, X, Y = _problem(15, 1000, 200, 20)
+    Xh = HipMatrix(X)
+    om = rng.random(200) + 0.5
+    x = SparseIterate(200)
+    if init == "WarmStart":
+        x.idx, x.val = [3, 1], [0.4, -0.2]
+    optCD = dict(maxIter=5000, optTol=1e-10, randomize=False)
+    N_RESIDUAL_COPIES[0] = 0
+    xg, r, sig = scaledLasso_hip(x, Xh, Y, 0.1, om, init, 5, 2.0, 50, 1e-6, optCD)
+    assert N_RESIDUAL_COPIES[0] == 1
+    xo = O.SparseIterate(200)
+    if init == "WarmStart":
+        xo[3] = 0.4
+        xo[1] = -0.2
+    so = O.scaledLasso_(xo, X, Y, 0.1, om, O.IterLassoOptions(maxIter=50, optTol=1e-6, initProcedure=init, sinit=5,
+                                                             sigmainit=2.0, optionsCD=O.CDOptions(**optCD)))
+    np.testing.assert_allclose(sig, so.sigma, rtol=1e-8)
+    np.testing.assert_allclose(xg.dense(), xo.dense(), rtol=0, atol=1e-8)
+    np.testing.assert_allclose(r, Y - X @ xg.dense(), rtol=0, atol=1e-8)
+    # a plain lasso on the same matrix afterwards binds its own y (the owner reference is this call's f.r)
+    Y2 = X[:, 50:55] @ rng.standard_normal(5) + rng.standard_normal(1000)
+    x2, _, _ = lasso(Xh, Y2, 0.05, None, OPT)
+    np.testing.assert_allclose(x2.dense(), O.lasso(X, Y2, 0.05, None, O.CDOptions(**OPT)).x.dense(), rtol=0, atol=1e-10)
+    Xh.close()
+
+
+def test_lasso_path_hipmatrix_method_moves_nothing_n_sized_and_restores_the_cache_mode():
+    rng, X, Y = _problem(16, 4000, 300, 30)
+    X *= rng.uniform(0.3, 3.0, size=300)
+    Xh = HipMatrix(X)
+    lams = [0.3, 0.2, 0.1, 0.05, 0.03]
+    N_RESIDUAL_COPIES[0] = 0
+    got_lams, path = LassoPath_hip(Xh, Y, lams, OPT)
+    assert N_RESIDUAL_COPIES[0] == 0 and gradient_cache_mode(Xh) == 1
+    lo, bo = O.LassoPath(X, Y, lams, O.CDOptions(**OPT))
+    for got, want in zip(path, bo):
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
+    # max_hat_s stops the path early and truncates lambdapath (lasso.jl:253-256)
+    got_lams, path = LassoPath_hip(Xh, Y, lams, OPT, max_hat_s=int(np.count_nonzero(bo[1])))
+    assert len(got_lams) == len(path) < len(lams)
+    # a caller who switched the cache off keeps it off through the path
+    ccall("cdh_set_gradient_cache", Xh.handle, i32(0))
+    LassoPath_hip(Xh, Y, lams[:2], OPT)
+    assert gradient_cache_mode(Xh) == 0
     Xh.close()

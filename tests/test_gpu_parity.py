@@ -521,6 +521,34 @@ def _bench_two_ranks_one_gpu(extra, env_extra=None):
     return last(a.stdout), last(b.stdout)
 
 
+def test_bench_gpus_2_without_a_launcher_two_ranks_one_gpu():
+    """`python bench.py --gpus 2 ...` with NO launcher and WORLD_SIZE unset (the form the driver's 1-GPU command
+    takes when only the number changes): the parent starts its own two ranks, never touches the GPU itself, and
+    relays exactly one JSON line with n_gpus == 2 -- the same sweep as one rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["CDH_P2P_SPIN_LIMIT"] = "4000000"
+    cmd = ["--steps", "2", "--warmup", "1", "--rows", "300000", "--cols", "96", "--planted", "10",
+           "--no-cpu-baseline", "--no-sparse", "--block", "16"]
+    a = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-rccl", "--exchange", "p2p"] + cmd,
+                       capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert a.returncode == 0, (a.stdout[-1500:], a.stderr[-3000:])
+    got = [l for l in a.stdout.splitlines() if l.strip()]
+    assert len(got) == 1 and got[0].startswith("{"), got      # stdout carries the result line and nothing else
+    ja = json.loads(got[0])
+    assert ja["n_gpus"] == 2 and ja["devices_by_rank"] == [0, 0] and ja["config"]["exchange"] == "p2p"
+    assert ja["exchange_stats"]["nranks"] == 2 and ja["exchange_stats"]["p2p_calls"] > 0
+    b = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + cmd,
+                       capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert b.returncode == 0, b.stderr[-2000:]
+    jb = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
+    assert ja["config"]["moved_per_sweep"] == jb["config"]["moved_per_sweep"]
+    assert abs(ja["config"]["last_maxH"] - jb["config"]["last_maxH"]) <= 1e-9 * abs(jb["config"]["last_maxH"])
+
+
 def test_bench_a_direct_exchange_probe_that_dies_costs_nothing():
     """--exchange auto (the default): the direct exchange meets the machine in child processes first.  Here every
     probe dies on the spot (os._exit, the stand-in for a GPU fault in a transport that has never run on this
