@@ -304,10 +304,10 @@ class _HipLoss(CoordinateDifferentiableFunction):
         return {"last": out[0], "max": out[1], "measured": int(out[2])}
 
     def cache_stats(self):
-        out = (C.c_int64 * 9)()
+        out = (C.c_int64 * 10)()
         check(self._L.cdh_cache_stats(self._h, out), self._h)
         return dict(zip(("passes", "settled_visits", "exact_visits", "reference_passes", "gram_batches", "gram_columns",
-                         "covariance_visits", "residual_catchups", "rollbacks"), [int(v) for v in out]))
+                         "covariance_visits", "residual_catchups", "rollbacks", "device_passes"), [int(v) for v in out]))
 
     def set_use_graph(self, on=True):
         check(self._L.cdh_set_use_graph(self._h, int(bool(on))), self._h)

@@ -102,6 +102,21 @@ struct GradCache {
     bool cov = true;                // env CDH_GC_COV
     double *d_g = nullptr, *d_G = nullptr, *h_g_pin = nullptr;
     int32_t* d_slot = nullptr;
+    // whole full passes on the device (gc_pass_device): g lives in d_g between passes and comes back only when host
+    // code asks for it.  g_host_ok / g_dev_ok say which copies are current (at least one always is while `valid`).
+    bool g_host_ok = true, g_dev_ok = false;
+    double *d_a = nullptr, *d_g_snap = nullptr, *d_beta_snap = nullptr, *d_qs = nullptr;
+    int64_t* d_pass_idx = nullptr;        // the pass's visit list (0-based), as uploaded last
+    std::vector<int64_t> pass_idx_host;   // ... and what it holds
+    int32_t *d_pos_of = nullptr, *d_upos = nullptr;
+    uint8_t* d_setflag = nullptr;
+    cdk::CovScanOut* d_scan = nullptr;
+    cdk::CovScanOut* h_scan = nullptr;    // pinned
+    int32_t* h_upos = nullptr;            // pinned, cap entries
+    bool a_dev_ok = false;                // d_a mirrors c.a
+    double yy = 0.0;                      // y'y over all shards (fp32 certificate margin), valid while yy_ok
+    bool yy_ok = false;
+    int64_t n_dev_passes = 0;
     int64_t dev_slots_cap = 0, dev_slots = 0;   // columns the device store can hold / holds
     int64_t cov_since_ref = 0;      // covariance-form visits since g was last taken from X itself
     int64_t refresh_after = 0;      // ... after which it is (kGcCovRefresh; env CDH_GC_REFRESH for tests)
@@ -147,6 +162,7 @@ struct cdh_handle_s {
     int screening = 1;            // 0 never, 1 the solves' full passes over sparse iterates, 2 cdh_pass too
     bool reuse_residual = false;  // warm starts skip initialize! when r is known to match beta
     bool r_consistent = false;    // r == y - X beta (up to rounding) for the handle's current iterate
+    int64_t r_roundings = 0;      // launches that have rewritten r (each rounds it to the storage type once) since it was last rebuilt
     bool chunk_dup = false;       // the current chunk's visit list repeats a coordinate
     std::vector<int32_t> stamp;   // duplicate detection scratch, size p
     struct GraphEntry { uint64_t key; hipGraphExec_t exec; unsigned exchanges; unsigned rccl; };
@@ -349,6 +365,7 @@ int32_t sync_r(cdh_handle h) {
         }));
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipStreamSynchronize(h->stream));   // the pinned staging arrays are reused
+        h->r_roundings += 1;
     }
     for (int64_t k : L) { h->r_pending[(size_t)k] = 0.0; h->r_in_pending[(size_t)k] = 0; }
     L.clear();
@@ -390,13 +407,13 @@ int32_t col_dots(cdh_handle h, int64_t j0, int64_t nc, const void* rvec, bool us
     return CDH_OK;
 }
 
-int32_t resid_moments_dev(cdh_handle h) {  // -> d_red[0..2] = sum r, sum r^2, sum w r^2
-    CHK(sync_r(h));
+int32_t resid_moments_dev(cdh_handle h, const void* vec = nullptr) {  // -> d_red[0..2] = sum v, sum v^2, sum w v^2 (v = r unless given)
+    if (!vec) { CHK(sync_r(h)); vec = h->r; }
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (h->nvec + kBlock - 1) / kBlock));
     CHK(dispatch(h, [&](auto* t) {
         using T = std::remove_pointer_t<decltype(t)>;
         hipLaunchKernelGGL(k_resid_moments<T>, dim3(grid), dim3(kBlock), 0, h->stream, h->nvec,
-                           (const T*)h->r, h->has_w ? (const T*)h->w : (const T*)nullptr, h->d_partials);
+                           (const T*)vec, h->has_w ? (const T*)h->w : (const T*)nullptr, h->d_partials);
         return CDH_OK;
     }));
     hipLaunchKernelGGL(k_sum_records, dim3(1), dim3(kBlock), 0, h->stream, h->d_partials, grid, h->d_red);
@@ -415,16 +432,20 @@ constexpr int64_t kGcCovWindow = 2048;      // positions one covariance-form chu
 constexpr int64_t kGcCovRefresh = 200000;   // covariance-form visits after which g is re-read from X
 constexpr int64_t kGcRowsPerNnz = 400;   // rows the problem must have per non-zero for the host-side fold to pay
 
+// every loss and both storage types (round 3); a weighted loss only once its weights are there (they are zero until
+// cdh_set_obs_weights: every a_k would be zero and nothing could be settled)
 inline bool gc_applicable(const cdh_handle_s* h) {
-    return h->gc.mode != 0 && h->dtype == CDH_F64 && !h->has_w && h->loss != CDH_WLS;
+    return h->gc.mode != 0 && (h->loss != CDH_WLS || h->has_w);
 }
 // g no longer describes r (y or the loss changed); with `columns` the Gram columns are gone too (X changed)
 void gc_invalidate(cdh_handle h, bool columns) {
     GradCache& c = h->gc;
     c.valid = false; c.beta_ok = false; c.q_valid = false;
+    c.g_host_ok = true; c.g_dev_ok = false;      // whatever g held is void; the next reference pass fills the host copy
     for (int64_t j : c.moved) { c.dbeta[(size_t)j] = 0.0; c.in_moved[(size_t)j] = 0; }
     c.moved.clear();
     if (columns) {
+        c.a_dev_ok = false;
         c.G.clear(); c.G.shrink_to_fit();
         std::fill(c.slot.begin(), c.slot.end(), -1);
         c.dev_slots = 0;                 // the device store is refilled from slot 0 (its memory is kept)
@@ -473,6 +494,7 @@ void gc_note_moves(cdh_handle h, const int64_t* idx0, int m) {
 // ---- initialize!: upload support, r = y - X beta ------------------------------------
 int32_t rebuild_residual(cdh_handle h) {
     drop_r_pending(h);
+    h->r_roundings = 1;               // r = y - X beta, summed in fp64 and rounded once
     const int64_t nnz = h->x.nnz();
     if (nnz == 0) {   // the cold start: beta = 0, r = y; nothing host-side is in flight, so no wait either
         HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
@@ -734,6 +756,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
         }
     }
     if (!launched) CHK(enqueue());
+    h->r_roundings += blocked ? (m + h->blockB - 1) / h->blockB + 1 : m + 1;   // one rewrite of r per launch that applies updates
     HIPCHK(h, hipGetLastError());
     if (h->prof) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     CHK(finish_chunk(h, idx0, m, maxH));
@@ -804,7 +827,7 @@ int32_t screened_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double*
         const int S = (int)std::min<int64_t>(scr, m - pos);
         std::memcpy(h->h_idx, idx0 + pos, sizeof(int64_t) * (size_t)S);
         HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)S, hipMemcpyHostToDevice, h->stream));
-        CHK(col_dots(h, 0, S, h->r, false, h->d_idx));
+        CHK(col_dots(h, 0, S, h->r, h->has_w, h->d_idx));   // X_k'W r, X_k'W X_k with observation weights
         HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * S, hipMemcpyDeviceToHost, h->stream));
         double rnorm = 0.0;
         if (h->loss == CDH_SQRT) {
@@ -847,7 +870,7 @@ int32_t screened_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double*
 // _cdPass! (coordinate_descent.jl:94-110)
 int32_t run_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, bool screen = false) {
     *maxH = 0.0;
-    if (screen && h->screening && !h->has_w && m >= 2 * kScreen && h->x.nnz() * 4 <= h->p) {
+    if (screen && h->screening && (h->loss != CDH_WLS || h->has_w) && m >= 2 * kScreen && h->x.nnz() * 4 <= h->p) {
         CHK(screened_full_pass(h, idx0, m, maxH));
     } else {
         for (int64_t off = 0; off < m; off += h->cap) {
@@ -918,6 +941,13 @@ void free_all(cdh_handle h) {
     if (h->gc.d_G) (void)hipFree(h->gc.d_G);
     if (h->gc.d_slot) (void)hipFree(h->gc.d_slot);
     if (h->gc.h_g_pin) (void)hipHostFree(h->gc.h_g_pin);
+    {
+        GradCache& c = h->gc;
+        void* dv[] = {c.d_a, c.d_g_snap, c.d_beta_snap, c.d_qs, c.d_pass_idx, c.d_pos_of, c.d_upos, c.d_setflag, c.d_scan};
+        for (void* q : dv) if (q) (void)hipFree(q);
+        if (c.h_scan) (void)hipHostFree(c.h_scan);
+        if (c.h_upos) (void)hipHostFree(c.h_upos);
+    }
     if (h->h_xchg) (void)hipHostFree(h->h_xchg);
     if (h->p2p_timeout) (void)hipHostFree(h->p2p_timeout);
     for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);
@@ -1099,6 +1129,7 @@ int32_t cdh_set_y(cdh_handle h, const void* host_y) {
     NEED_P(h, host_y);
     h->r_consistent = false;
     gc_invalidate(h, false);
+    h->gc.yy_ok = false;
     drop_r_pending(h);                 // r = copy(y) below
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(h->y, host_y, (size_t)h->n * h->esz, hipMemcpyHostToDevice, h->stream));
@@ -1157,6 +1188,7 @@ int32_t cdh_set_loss(cdh_handle h, int32_t loss) {
 static int32_t cdh_generate_impl(cdh_handle h, uint64_t seed, int64_t s, double noise, double* out_beta_star) {
     if (s < 0 || s > h->p) return fail(h, CDH_BAD_ARG, "need 0 <= s <= p");
     gc_invalidate(h, true);
+    h->gc.yy_ok = false;
     drop_r_pending(h);
     HIPCHK(h, hipSetDevice(h->device));
     // planted coefficients: beta*_j = z_j (1 + u_j) (benchmark/cd_bench.jl:14), stream 2
@@ -1527,13 +1559,14 @@ static int32_t cdh_cache_drift_impl(cdh_handle h, int32_t rereference_now, doubl
     return CDH_OK;
 }
 
-int32_t cdh_cache_stats(cdh_handle h, int64_t* out9) {
+int32_t cdh_cache_stats(cdh_handle h, int64_t* out10) {
     NEED_H(h);
-    NEED_P(h, out9);
+    NEED_P(h, out10);
     const GradCache& c = h->gc;
-    out9[0] = c.n_passes; out9[1] = c.n_certified; out9[2] = c.n_exact;
-    out9[3] = c.n_validate; out9[4] = c.n_batches; out9[5] = c.n_columns;
-    out9[6] = c.n_cov; out9[7] = c.n_reconcile; out9[8] = c.n_rollbacks;
+    out10[0] = c.n_passes; out10[1] = c.n_certified; out10[2] = c.n_exact;
+    out10[3] = c.n_validate; out10[4] = c.n_batches; out10[5] = c.n_columns;
+    out10[6] = c.n_cov; out10[7] = c.n_reconcile; out10[8] = c.n_rollbacks;
+    out10[9] = c.n_dev_passes;
     return CDH_OK;
 }
 

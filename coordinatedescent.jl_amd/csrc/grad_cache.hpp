@@ -41,11 +41,11 @@ int32_t gc_size(cdh_handle h) {   // first use on this handle
     const int64_t launches = (h->p + kCrossA - 1) / kCrossA;      // column groups
     const int64_t nslabs = (h->nvec + kCrossSlab - 1) / kCrossSlab;
     // gridDim.x = column groups in flight (super-groups of 4 x 64 columns; env CDH_CROSS_GX, default 4), gridDim.y = row lanes; never more blocks
-    // than stay resident, 2 per CU (a partly filled second round would double the time)
+    // than stay resident, kCrossOcc per CU (a partly filled second round would double the time)
     const char* gxe = getenv("CDH_CROSS_GX");
     const int64_t nsuper = (launches + kGramWaves - 1) / kGramWaves;   // a block's four waves take four column groups
     c.cross_GX = (int)std::max<int64_t>(1, std::min<int64_t>(nsuper, gxe ? atoi(gxe) : 4));
-    c.cross_J = (int)std::max<int64_t>(1, std::min<int64_t>(nslabs, (2 * (int64_t)h->cus) / c.cross_GX));
+    c.cross_J = (int)std::max<int64_t>(1, std::min<int64_t>(nslabs, ((int64_t)kCrossOcc * h->cus) / c.cross_GX));
     // (a handle whose first sizing failed may be asked again: what a failed attempt got was freed below)
     bool fits = hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec) == hipSuccess &&
                 hipMalloc((void**)&c.d_cross_part, sizeof(double) * (size_t)launches * (size_t)c.cross_J * kCrossRec) == hipSuccess &&
@@ -79,9 +79,24 @@ int32_t gc_dev_upload(cdh_handle h) {
                     // pinned staging for g on its way down and back (pageable copies are staged by the
                     // runtime, one hidden synchronisation each: two per chunk of visits)
                     hipHostMalloc((void**)&c.h_g_pin, sizeof(double) * 2 * (size_t)p) == hipSuccess;
+        // ... and what a whole full pass on the device needs (gc_pass_device): a, the snapshots, the per-coordinate
+        // position / settled flag, the compacted visit list, the per-visit r'r, the scan's counters
+        fits = fits && hipMalloc((void**)&c.d_a, sizeof(double) * (size_t)p) == hipSuccess &&
+               hipMalloc((void**)&c.d_g_snap, sizeof(double) * (size_t)p) == hipSuccess &&
+               hipMalloc((void**)&c.d_beta_snap, sizeof(double) * (size_t)p) == hipSuccess &&
+               hipMalloc((void**)&c.d_qs, sizeof(double) * (size_t)h->cap) == hipSuccess &&
+               hipMalloc((void**)&c.d_pass_idx, sizeof(int64_t) * (size_t)h->cap) == hipSuccess &&
+               hipMalloc((void**)&c.d_pos_of, sizeof(int32_t) * (size_t)p) == hipSuccess &&
+               hipMalloc((void**)&c.d_upos, sizeof(int32_t) * (size_t)h->cap) == hipSuccess &&
+               hipMalloc((void**)&c.d_setflag, (size_t)p) == hipSuccess &&
+               hipMalloc((void**)&c.d_scan, sizeof(cdk::CovScanOut)) == hipSuccess &&
+               hipHostMalloc((void**)&c.h_scan, sizeof(cdk::CovScanOut)) == hipSuccess &&
+               hipHostMalloc((void**)&c.h_upos, sizeof(int32_t) * (size_t)h->cap) == hipSuccess;
         if (!fits) (void)hipGetLastError();
         CHK(all_ranks_agree(h, fits, &fits));
         if (!fits) { c.cov = false; return CDH_OK; }
+        HIPCHK(h, hipMemsetAsync(c.d_qs, 0, sizeof(double) * (size_t)h->cap, h->stream));
+        c.g_dev_ok = false; c.a_dev_ok = false;
     }
     if (have > c.dev_slots_cap) {   // grow the store (64 columns at a time, at most kGcMaxBytes), keeping what is there
         const int64_t cap = std::min<int64_t>((have + 63) / 64 * 64 + 64, (int64_t)(kGcMaxBytes / sizeof(double)) / std::max<int64_t>(p, 1));
@@ -102,6 +117,56 @@ int32_t gc_dev_upload(cdh_handle h) {
     c.dev_slots = have;
     HIPCHK(h, hipMemcpyAsync(c.d_slot, c.slot.data(), sizeof(int32_t) * (size_t)p, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CDH_OK;
+}
+
+// ---- which copy of g is current ------------------------------------------------------------------------------
+// The device-side passes leave g in d_g; host code that reads c.g (the legacy walk, the choice of columns to
+// fetch, a re-reference's drift measurement) asks for it first.  The other direction likewise.
+int32_t gc_need_host_g(cdh_handle h) {
+    GradCache& c = h->gc;
+    if (c.g_host_ok) return CDH_OK;
+    HIPCHK(h, hipMemcpyAsync(c.h_g_pin, c.d_g, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(c.g.data(), c.h_g_pin, sizeof(double) * (size_t)h->p);
+    c.g_host_ok = true;
+    return CDH_OK;
+}
+int32_t gc_need_dev_g(cdh_handle h) {
+    GradCache& c = h->gc;
+    if (!c.a_dev_ok) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));                 // h_g_pin's second half doubles as staging for a
+        std::memcpy(c.h_g_pin + h->p, c.a.data(), sizeof(double) * (size_t)h->p);
+        HIPCHK(h, hipMemcpyAsync(c.d_a, c.h_g_pin + h->p, sizeof(double) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        c.a_dev_ok = true;
+    }
+    if (c.g_dev_ok) return CDH_OK;
+    std::memcpy(c.h_g_pin, c.g.data(), sizeof(double) * (size_t)h->p);
+    HIPCHK(h, hipMemcpyAsync(c.d_g, c.h_g_pin, sizeof(double) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));                     // the staging buffer is free again
+    c.g_dev_ok = true;
+    return CDH_OK;
+}
+
+// What the certificates must allow for besides the 1e-9 relative margin: with fp32 storage the residual is rounded to
+// fp32 by every launch that rewrites it, and the streamed kernels' own dots carry fp32 chunk sums -- the cache's g,
+// carried in fp64 from Gram entries summed in fp64, describes a slightly DIFFERENT residual than the one the exact
+// visit would read.  A rounding of relative size 2^-24 per element and rewrite, U rewrites since the residual was last
+// rebuilt, uncorrelated with the column: |X_k'(r_fp32 - r)| ~ 2^-24 sqrt(U a_k r'r / n); with r'r <= y'y along a path
+// and a factor 64 of safety:   cert_abs sqrt(a_k),  cert_abs = 64 * 2^-24 * sqrt((U + 1) y'y / n).   fp64 storage: 0.
+int32_t gc_cert_abs(cdh_handle h, double* out) {
+    GradCache& c = h->gc;
+    *out = 0.0;
+    if (h->dtype != CDH_F32) return CDH_OK;
+    if (!c.yy_ok) {
+        CHK(resid_moments_dev(h, h->y));
+        HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        c.yy = h->h_red[1];
+        c.yy_ok = true;
+    }
+    *out = 64.0 * 5.9604644775390625e-8 * std::sqrt((double)(h->r_roundings + 1) * c.yy / (double)h->n_total);
     return CDH_OK;
 }
 
@@ -149,8 +214,10 @@ bool gc_ready_for_cov(cdh_handle h, const int64_t* idx0, int64_t m) {
 
 
 // Visits idx0[0..m) from the cache alone: record from (g, G) -> the B scalar updates -> g update, block by
-// block; nothing n-sized is touched.  r learns about the moves later (sync_r).
-template <int NG> int32_t launch_cov_chunk(cdh_handle h, int m) {
+// block; nothing n-sized is touched.  r learns about the moves later (sync_r).  With `chk` (a device-side full
+// pass: the visit list is the scan's compaction, d_upos its positions) the g update also re-checks the skipped
+// positions the block answers for (k_cov_gupdate_chk).
+template <int NG> int32_t launch_cov_chunk(cdh_handle h, int m, bool chk = false, int m_pass = 0) {
     using R = GramRec<NG>;
     constexpr int B = R::B;
     GradCache& c = h->gc;
@@ -159,40 +226,51 @@ template <int NG> int32_t launch_cov_chunk(cdh_handle h, int m) {
         hipLaunchKernelGGL((k_cov_record<NG>), dim3(1), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot, h->p, h->d_idx, pos0, nb,
                            h->d_ctrl, h->d_red);
         hipLaunchKernelGGL((k_gram_scalar<NG>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb, h->chunk_dup ? 1 : 0, h->d_ctrl,
-                           h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos0);
-        hipLaunchKernelGGL(k_cov_gupdate, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot, h->p,
-                           h->d_idx, h->d_hs, pos0, nb);
+                           h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos0, c.d_qs);
+        if (chk)
+            hipLaunchKernelGGL(k_cov_gupdate_chk, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot,
+                               c.d_a, h->omega, h->d_ctrl, h->p, h->d_idx, h->d_hs, c.d_qs, c.d_upos, c.d_pos_of, c.d_setflag,
+                               pos0, nb, m_pass, pos0 + nb >= m ? 1 : 0, h->d_red + R::OFF_Q, c.d_scan);
+        else
+            hipLaunchKernelGGL(k_cov_gupdate, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot, h->p,
+                               h->d_idx, h->d_hs, pos0, nb);
     }
     return CDH_OK;
 }
+// the width of the handle's blocked sweep where it has one (same recurrence, same kernel), else 16
+int32_t launch_cov_blocks(cdh_handle h, int m, bool chk = false, int m_pass = 0) {
+    const int B = (h->mode == CDH_SWEEP_BLOCK && h->blockB >= 16) ? h->blockB : 16;
+    if (B == 64) return launch_cov_chunk<4>(h, m, chk, m_pass);
+    if (B == 32) return launch_cov_chunk<2>(h, m, chk, m_pass);
+    return launch_cov_chunk<1>(h, m, chk, m_pass);
+}
 
-// enqueue the visits, bring the results and the updated g back into staging (h_hs / h_newval / h_touched /
-// h_ctrl, c.g_new) -- nothing on the host has changed yet
-int32_t cov_run(cdh_handle h, const int64_t* idx0, int m) {
+// enqueue the visits, bring the results back into staging (h_hs / h_newval / h_touched / h_ctrl) -- nothing on the
+// host has changed yet.  g stays on the device; with `want_g` (the legacy walk re-checks skipped certificates on
+// the host) the updated g also comes back into c.g_new.
+int32_t cov_run(cdh_handle h, const int64_t* idx0, int m, bool want_g) {
     GradCache& c = h->gc;
+    CHK(gc_need_dev_g(h));
     std::memcpy(h->h_idx, idx0, sizeof(int64_t) * (size_t)m);
     note_duplicates(h, idx0, m);
     HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
-    std::memcpy(c.h_g_pin, c.g.data(), sizeof(double) * (size_t)h->p);
-    HIPCHK(h, hipMemcpyAsync(c.d_g, c.h_g_pin, sizeof(double) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
     h->ctrl.maxH = 0.0;
     h->ctrl.domain_error = 0;
     h->ctrl.q_carry = c.q;
     CHK(upload_ctrl(h));
-    // the width of the handle's blocked sweep where it has one (same recurrence, same kernel), else 16
-    const int B = (h->mode == CDH_SWEEP_BLOCK && h->blockB >= 16) ? h->blockB : 16;
-    if (B == 64) CHK(launch_cov_chunk<4>(h, m));
-    else if (B == 32) CHK(launch_cov_chunk<2>(h, m));
-    else CHK(launch_cov_chunk<1>(h, m));
+    CHK(launch_cov_blocks(h, m));
     HIPCHK(h, hipGetLastError());
-    c.g_new.resize((size_t)h->p);
-    HIPCHK(h, hipMemcpyAsync(c.h_g_pin + h->p, c.d_g, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost, h->stream));
+    if (want_g) {
+        c.g_new.resize((size_t)h->p);
+        HIPCHK(h, hipMemcpyAsync(c.h_g_pin + h->p, c.d_g, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(h, hipMemcpyAsync(h->h_hs, h->d_hs, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_newval, h->d_newval, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_touched, h->d_touched, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    std::memcpy(c.g_new.data(), c.h_g_pin + h->p, sizeof(double) * (size_t)h->p);
+    if (want_g) std::memcpy(c.g_new.data(), c.h_g_pin + h->p, sizeof(double) * (size_t)h->p);
+    c.g_host_ok = false;              // d_g has moved on; c.g is the gradient BEFORE the chunk until it is accepted
     return CDH_OK;
 }
 // the staged results of visit i become real: SparseIterate writes, the move noted for r, maxH
@@ -205,41 +283,46 @@ void cov_apply_visit(cdh_handle h, int64_t k, int i) {
     h->r_pending[(size_t)k] += hv;
     if (hv == hv && h->gc.beta_ok) h->gc.beta_ref[(size_t)k] += hv;
 }
-void cov_accept_tail(cdh_handle h, int m, double* maxH) {
+// the chunk is accepted: maxH, r'r, the counters; `have_g_new`: c.g_new is the gradient after the chunk
+void cov_accept_tail(cdh_handle h, int m, double* maxH, bool have_g_new) {
     GradCache& c = h->gc;
     const double mh = h->h_ctrl->maxH;
     if (mh > *maxH) *maxH = mh;
     if (h->h_ctrl->domain_error) h->domain_error = true;
     if (h->loss == CDH_SQRT) c.q = h->h_ctrl->q_carry;
-    c.g.swap(c.g_new);
+    if (have_g_new) { c.g.swap(c.g_new); c.g_host_ok = true; }
     c.n_cov += m;
     c.cov_since_ref += m;
     bool nan = false;
     for (int i = 0; i < m; ++i) nan = nan || (h->h_hs[i] != h->h_hs[i]);
     if (nan) gc_invalidate(h, false);   // r turns NaN at the catch-up, as in the reference; the cache knows nothing any more
 }
-// a chunk in which every position is visited (the active passes of a solve)
+// a chunk in which every position is visited (the active passes of a solve): g never leaves the device
 int32_t cov_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
-    CHK(cov_run(h, idx0, m));
+    CHK(cov_run(h, idx0, m, false));
     for (int i = 0; i < m; ++i) cov_apply_visit(h, idx0[i], i);
-    cov_accept_tail(h, m, maxH);
+    cov_accept_tail(h, m, maxH, false);
     return CDH_OK;
 }
-// the visits never happened: beta on the device goes back to what the host-side iterate still says
+// the visits never happened: beta on the device goes back to what the host-side iterate still says, and the
+// device's g (which has seen the chunk's moves) is void -- c.g still holds the gradient from before the chunk
 int32_t cov_reject(cdh_handle h, const int64_t* idx0, int m) {
+    GradCache& c = h->gc;
     for (int i = 0; i < m; ++i) { h->h_idx[i] = idx0[i]; h->h_hs[i] = h->x.get(idx0[i]); }
     HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_hs, h->h_hs, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_scatter_f64, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, h->beta, h->d_idx, h->d_hs, m);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    c.g_host_ok = true; c.g_dev_ok = false;
     return CDH_OK;
 }
 
-// g = X'r and a = diag(X'X) from one dots-only pass over all of X: the new reference point
+// g = X'r and a = diag(X'X) (with observation weights: X'Wr, diag(X'WX)) from one dots-only pass over all of X: the
+// new reference point
 int32_t gc_validate(cdh_handle h) {
     GradCache& c = h->gc;
-    CHK(col_dots(h, 0, h->p, h->r, false));
+    CHK(col_dots(h, 0, h->p, h->r, h->has_w));
     std::vector<double> cd((size_t)(2 * h->p));
     HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * h->p, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -247,6 +330,7 @@ int32_t gc_validate(cdh_handle h) {
     for (int64_t j : c.moved) { c.dbeta[(size_t)j] = 0.0; c.in_moved[(size_t)j] = 0; }
     c.moved.clear();
     c.valid = true;
+    c.g_host_ok = true; c.g_dev_ok = false; c.a_dev_ok = false;
     c.n_validate += 1;
     c.cov_since_ref = 0;
     return CDH_OK;
@@ -265,7 +349,7 @@ int32_t gc_rereference(cdh_handle h) {
     if (comparable)
         for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) comparable = false;
     std::vector<double> carried;
-    if (comparable) { gc_fold(h); carried = c.g; }
+    if (comparable) { gc_fold(h); CHK(gc_need_host_g(h)); carried = c.g; }
     gc_invalidate(h, false);
     CHK(gc_validate(h));
     c.beta_ok = beta_known;
@@ -306,8 +390,13 @@ int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
         HIPCHK(h, hipMemcpyAsync(c.d_cols, todo.data() + b0, sizeof(int64_t) * (size_t)nbc, hipMemcpyHostToDevice, h->stream));
         CHK(dispatch(h, [&](auto* t) {
             using T = std::remove_pointer_t<decltype(t)>;
-            hipLaunchKernelGGL(k_cross<T>, dim3((unsigned)c.cross_GX, (unsigned)c.cross_J), dim3(64 * kGramWaves), 0, h->stream,
-                               (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc, c.d_cross_part);
+            const dim3 grid((unsigned)c.cross_GX, (unsigned)c.cross_J), block(64 * kGramWaves);
+            if (h->has_w)   // G = X'WX (CDWeightedLSLoss: cd_differentiable_function.jl:177-182)
+                hipLaunchKernelGGL((k_cross<T, true>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc,
+                                   (const T*)h->w, c.d_cross_part);
+            else
+                hipLaunchKernelGGL((k_cross<T, false>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc,
+                                   (const T*)nullptr, c.d_cross_part);
             return CDH_OK;
         }));
         hipLaunchKernelGGL(k_cross_reduce, dim3(kCrossRec / 256, (unsigned)launches), dim3(256), 0, h->stream, c.d_cross_part,
@@ -341,26 +430,34 @@ bool gc_fold_device(cdh_handle h) {
     if (!c.cov || !c.d_G || !c.h_g_pin || c.dev_slots != (int64_t)c.G.size()) return false;
     const int64_t M = (int64_t)c.moved.size();
     if (M > h->cap) return false;
+    if (gc_need_dev_g(h) != CDH_OK) { (void)hipGetLastError(); return false; }
     for (int64_t i = 0; i < M; ++i) { h->h_idx[i] = c.moved[(size_t)i]; h->h_hs[i] = c.dbeta[(size_t)c.moved[(size_t)i]]; }
-    std::memcpy(c.h_g_pin, c.g.data(), sizeof(double) * (size_t)h->p);
-    bool ok = hipMemcpyAsync(c.d_g, c.h_g_pin, sizeof(double) * (size_t)h->p, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
-              hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)M, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+    bool ok = hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)M, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
               hipMemcpyAsync(h->d_hs, h->h_hs, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, h->stream) == hipSuccess;
     for (int64_t pos0 = 0; ok && pos0 < M; pos0 += 64)
         hipLaunchKernelGGL(k_cov_gupdate, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot,
                            h->p, h->d_idx, h->d_hs, (int)pos0, (int)std::min<int64_t>(64, M - pos0));
-    ok = ok && hipGetLastError() == hipSuccess &&
-         hipMemcpyAsync(c.h_g_pin + h->p, c.d_g, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
-         hipStreamSynchronize(h->stream) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); return false; }
-    std::memcpy(c.g.data(), c.h_g_pin + h->p, sizeof(double) * (size_t)h->p);
+    ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;   // the staging arrays are reused
+    if (!ok) {                        // a HIP failure mid-fold: the device copy is void
+        (void)hipGetLastError();
+        if (c.g_host_ok) c.g_dev_ok = false;      // c.g (host) is still the unfolded gradient: the host loop folds it
+        else gc_invalidate(h, false);             // no copy left: the next full pass takes g afresh from X
+        return false;
+    }
+    c.g_host_ok = false;              // g stays where the next pass wants it
     return true;
 }
 
 void gc_fold(cdh_handle h) {
     GradCache& c = h->gc;
     if (c.moved.empty()) return;
+    // (the host copy is needed only for the host-side fallback; when the device folds, it is merely marked stale)
     const bool on_device = gc_fold_device(h);
+    if (!on_device) {
+        if (!c.valid) return;                     // invalidated by a failed device fold (moved is already empty)
+        (void)gc_need_host_g(h);
+        c.g_dev_ok = false;
+    }
     for (int64_t j : c.moved) {
         const double d = c.dbeta[(size_t)j];
         if (!on_device && d != 0.0) {
@@ -373,6 +470,122 @@ void gc_fold(cdh_handle h) {
 }
 
 int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH);
+
+// The inactive coordinates of `enter` are about to move and have no Gram column: fetch their columns now, the batch
+// filled with the inactive coordinates nearest their certificate (on a lambda path: the next entrants).  Needs the
+// host copy of g.  `cert(k)`: the bound |g_k| is compared with; `ratio(k)`: |g_k| relative to its threshold.
+template <typename Cert, typename Ratio>
+int32_t gc_fetch_entering(cdh_handle h, std::vector<int64_t>& enter, Cert&& cert, Ratio&& ratio) {
+    GradCache& c = h->gc;
+    const size_t room = (kCrossB - enter.size() % kCrossB) % kCrossB;
+    std::vector<std::pair<double, int64_t>> near;
+    for (int64_t k = 0; k < h->p && room > 0; ++k)
+        if (c.slot[(size_t)k] < 0 && h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0 && std::fabs(c.g[(size_t)k]) <= cert(k))
+            near.emplace_back(ratio(k), k);
+    const size_t take = std::min(room, near.size());
+    std::partial_sort(near.begin(), near.begin() + (std::ptrdiff_t)take, near.end(), std::greater<std::pair<double, int64_t>>());
+    for (size_t i = 0; i < take; ++i) enter.push_back(near[i].second);
+    return gc_fetch(h, enter);
+}
+
+// ---- a whole full pass on the device ----------------------------------------------------------------------------
+// Round 2 walked the pass on the host in windows of <= 2048 positions: g went down and came back per window, and the
+// certificates of the skipped positions were re-checked on the host with p flops per mover -- 2862 copies and ~40 ms
+// of host time in cfg3's 140 ms.  Here g stays in d_g: k_cov_scan classifies all m positions and compacts the
+// unsettled ones (one small copy back: their number and positions, to check that each has its Gram column); the
+// covariance-form blocks then run over that list, their g update re-checking on the way every skipped certificate
+// the block answers for (k_cov_gupdate_chk); one more copy brings back the visits' results and the verdict.  Two
+// synchronisations per pass, nothing p-sized on the bus.  A failed re-check (never seen in cfg3; forced in
+// test_covariance_chunks_roll_back...) restores g and beta from the scan's snapshot and leaves the pass to the
+// windowed walk below, which knows how to stop at the offending position.
+enum { kDevDone = 0, kDevPlain = 1, kDevWalk = 2 };
+template <typename Cert, typename Ratio>
+int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, double cert_abs, Cert&& cert, Ratio&& ratio,
+                       int* outcome) {
+    GradCache& c = h->gc;
+    *outcome = kDevWalk;
+    if (!c.cov || !c.d_G || !c.d_scan || !c.moved.empty() || c.dev_slots != (int64_t)c.G.size() || m > h->cap) return CDH_OK;
+    if (h->loss == CDH_SQRT && !c.q_valid) return CDH_OK;
+    note_duplicates(h, idx0, (int)m);
+    if (h->chunk_dup) return CDH_OK;            // a caller-made list that repeats a coordinate: positions are not unique
+    CHK(gc_need_dev_g(h));
+    const bool host_ok_before = c.g_host_ok;
+    if ((int64_t)c.pass_idx_host.size() != m || std::memcmp(c.pass_idx_host.data(), idx0, sizeof(int64_t) * (size_t)m) != 0) {
+        std::memcpy(h->h_idx, idx0, sizeof(int64_t) * (size_t)m);
+        HIPCHK(h, hipMemcpyAsync(c.d_pass_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+        c.pass_idx_host.assign(idx0, idx0 + m);
+    }
+    int cnt = 0;
+    for (int attempt = 0;; ++attempt) {
+        h->ctrl.maxH = 0.0;
+        h->ctrl.domain_error = 0;
+        h->ctrl.q_carry = c.q;
+        h->ctrl.cert_abs = cert_abs;
+        CHK(upload_ctrl(h));
+        hipLaunchKernelGGL(k_cov_scan, dim3(1), dim3(1024), 0, h->stream, c.d_g, c.d_a, h->beta, h->omega, h->d_ctrl, c.d_pass_idx, (int)m,
+                           h->p, c.d_pos_of, c.d_setflag, c.d_upos, h->d_idx, c.d_g_snap, c.d_beta_snap, c.d_scan);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(c.h_scan, c.d_scan, sizeof(cdk::CovScanOut), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(c.h_upos, c.d_upos, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        cnt = c.h_scan->count;
+        if (c.h_scan->nzero > 0) return CDH_OK;     // a settled coordinate with g == 0 exactly: its bookkeeping differs; the walk knows
+        std::vector<int64_t> enter;
+        for (int j = 0; j < cnt; ++j) {
+            const int64_t k = idx0[c.h_upos[j]];
+            if (c.slot[(size_t)k] < 0) enter.push_back(k);
+        }
+        if (enter.empty()) break;
+        if (attempt > 0) return CDH_OK;             // cannot happen (the fetch below gave every one of them a column)
+        if ((int)enter.size() > kGcBusy) {          // busy: back off (1, 2, 4 ... 16 plain passes) so that dense problems pay next to nothing
+            c.cooldown = c.backoff; c.backoff = std::min(16, 2 * c.backoff);
+            gc_invalidate(h, false);
+            *outcome = kDevPlain;
+            return CDH_OK;
+        }
+        CHK(gc_need_host_g(h));
+        CHK(gc_fetch_entering(h, enter, cert, ratio));
+        if (c.mode == 0) { *outcome = kDevPlain; return CDH_OK; }
+    }
+    c.backoff = 1;
+    if (cnt > 0) {
+        h->chunk_dup = false;
+        CHK(launch_cov_blocks(h, cnt, true, (int)m));
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(h->h_hs, h->d_hs, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_newval, h->d_newval, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_touched, h->d_touched, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(c.h_scan, c.d_scan, sizeof(cdk::CovScanOut), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if ((int64_t)c.h_scan->bad_pos < m) {       // a skipped certificate did not survive the pass's own moves: undo
+            hipLaunchKernelGGL(k_cov_restore, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, h->beta, c.d_g_snap,
+                               c.d_beta_snap, h->p);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            c.g_host_ok = host_ok_before;           // d_g is the gradient of the pass's start again
+            c.n_rollbacks += 1;
+            return CDH_OK;                          // -> the windowed walk
+        }
+        c.g_host_ok = false;
+    } else {
+        *h->h_ctrl = h->ctrl;                       // nothing ran: maxH 0, no domain error, r'r as it was
+    }
+    // bookkeeping in visit order: what the reference's SparseIterate would have seen
+    int j = 0;
+    for (int64_t q = 0; q < m; ++q) {
+        const int64_t k = idx0[q];
+        if (j < cnt && c.h_upos[j] == (int32_t)q) { cov_apply_visit(h, k, j); ++j; }
+        else {                                       // settled, g_k != 0: LS stores x[k] += b/a first, cdprox! zeroes it
+            if (h->loss != CDH_SQRT) h->x.set(k, 1.0);
+            h->x.set(k, 0.0);
+        }
+    }
+    c.n_exact += cnt; c.n_certified += m - cnt; c.n_dev_passes += 1;
+    cov_accept_tail(h, cnt, maxH, false);
+    *outcome = kDevDone;
+    return CDH_OK;
+}
 
 // A full pass over idx0[0..m) from the cache.  *handled = false: the caller runs the pass the plain way.
 int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, bool* handled) {
@@ -398,6 +611,8 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     if (c.cooldown > 0) { c.cooldown -= 1; if (c.valid) gc_invalidate(h, false); return CDH_OK; }
     CHK(gc_size(h));
     if (c.mode == 0) return CDH_OK;
+    double cert_abs = 0.0;            // fp32 storage: what the certificates allow for the residual's rounding
+    CHK(gc_cert_abs(h, &cert_abs));
     const double lam = h->ctrl.lambda0, nt = (double)h->n_total;
     const std::vector<double>& om = h->h_omega;
     // 1. a current g: fold the pending moves, fetching the columns that are missing; too many missing (or no
@@ -422,15 +637,19 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
         const double w = h->has_omega ? om[(size_t)k] : 1.0;
         return (h->loss == CDH_SQRT ? lam * w * rnorm : lam * nt * w) * (1.0 - 1e-9);
     };
+    // the bound a certificate compares |g_k| with (k_cov_scan's, on the host)
+    auto cert = [&](int64_t k) { return thr_of(k) - cert_abs * std::sqrt(c.a[(size_t)k]); };
+    auto ratio = [&](int64_t k) { return std::fabs(c.g[(size_t)k]) / thr_of(k); };
     // settled = the exact visit would leave beta_k at zero and r untouched (zero columns take the exact path)
     auto settled = [&](int64_t k) {
-        return h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0 && std::fabs(c.g[(size_t)k]) <= thr_of(k);
+        return h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0 && std::fabs(c.g[(size_t)k]) <= cert(k);
     };
     if (!want.empty()) {
         // fill the last batch of 32 with the inactive coordinates nearest their threshold: the likeliest to
         // enter the support next (on a lambda path: at one of the next lambdas)
         const size_t room = (kCrossB - want.size() % kCrossB) % kCrossB;
         if (room > 0 && c.moved.empty()) {
+            CHK(gc_need_host_g(h));
             CHK(refresh_rnorm());
             std::vector<std::pair<double, int64_t>> near;
             for (int64_t k = 0; k < h->p; ++k)
@@ -445,8 +664,19 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     }
     for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return fail(h, CDH_BAD_ARG, "gradient cache: a moved coordinate has no Gram column");
     gc_fold(h);
+    if (!c.valid) return CDH_OK;      // (a device fold that failed hard leaves no gradient: the pass runs the plain way)
     CHK(refresh_rnorm());
-    // 2. inactive coordinates about to move: many of them means the pass is mostly real visits anyway
+    // 2. the whole pass on the device where it can be (g stays there); else -- and after a failed re-check -- the
+    //    windowed walk below, with g on the host
+    {
+        int outcome = kDevWalk;
+        CHK(gc_pass_device(h, idx0, m, maxH, cert_abs, cert, ratio, &outcome));
+        if (outcome == kDevDone) { *handled = true; c.n_passes += 1; return CDH_OK; }
+        if (outcome == kDevPlain) return CDH_OK;
+        if (!c.valid) return CDH_OK;
+    }
+    CHK(gc_need_host_g(h));
+    // 2'. inactive coordinates about to move: many of them means the pass is mostly real visits anyway
     std::vector<int64_t> enter;
     for (int64_t i = 0; i < m; ++i) {
         const int64_t k = idx0[i];
@@ -462,15 +692,7 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     c.backoff = 1;
     if (!enter.empty()) {
         // their columns now, with the nearest other candidates filling the batch
-        const size_t room = (kCrossB - enter.size() % kCrossB) % kCrossB;
-        std::vector<std::pair<double, int64_t>> near;
-        for (int64_t k = 0; k < h->p && room > 0; ++k)
-            if (c.slot[(size_t)k] < 0 && h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0 && settled(k))
-                near.emplace_back(std::fabs(c.g[(size_t)k]) / thr_of(k), k);
-        const size_t take = std::min(room, near.size());
-        std::partial_sort(near.begin(), near.begin() + (std::ptrdiff_t)take, near.end(), std::greater<std::pair<double, int64_t>>());
-        for (size_t i = 0; i < take; ++i) enter.push_back(near[i].second);
-        CHK(gc_fetch(h, enter));
+        CHK(gc_fetch_entering(h, enter, cert, ratio));
         if (c.mode == 0) return CDH_OK;
     }
     *handled = true;
@@ -481,6 +703,7 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     const int64_t maxlen = std::min<int64_t>(h->cap, std::max<int64_t>(4 * B, 64));
     int64_t pos = 0;
     while (pos < m) {
+        CHK(gc_need_host_g(h));       // (a covariance-form chunk or a device fold below leaves g on the device)
         const int64_t k = idx0[pos];
         if (settled(k)) {
             if (h->loss != CDH_SQRT && c.g[(size_t)k] != 0.0) h->x.set(k, 1.0);   // x[k] += b/a stores a slot ...
@@ -509,7 +732,7 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
                     std::vector<int64_t> vis(upos.size());
                     for (size_t i = 0; i < upos.size(); ++i) vis[i] = idx0[upos[i]];
                     const int mv = (int)vis.size();
-                    CHK(cov_run(h, vis.data(), mv));
+                    CHK(cov_run(h, vis.data(), mv, true));
                     // re-check the skipped positions in visit order, carrying g through the chunk's moves
                     std::vector<double> gv(c.g);
                     double q_run = c.q;                  // sqrt-lasso: ||r|| moves with every visit, and the thresholds with it
@@ -517,7 +740,7 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
                     int64_t bad = -1;
                     size_t iu = 0;
                     auto settled_at = [&](int64_t kq) {
-                        return h->x.get(kq) == 0.0 && c.a[(size_t)kq] > 0.0 && std::fabs(gv[(size_t)kq]) <= thr_of(kq);
+                        return h->x.get(kq) == 0.0 && c.a[(size_t)kq] > 0.0 && std::fabs(gv[(size_t)kq]) <= cert(kq);
                     };
                     for (int64_t q = pos; q < wend; ++q) {
                         if (iu < upos.size() && upos[iu] == q) {
@@ -547,7 +770,7 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
                                 c.n_certified += 1;
                             }
                         }
-                        cov_accept_tail(h, mv, maxH);
+                        cov_accept_tail(h, mv, maxH, true);
                         if (h->loss == CDH_SQRT) rnorm = std::sqrt(c.q);
                         break;
                     }

@@ -438,7 +438,8 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
                                                     Ctrl* ctrl, double* beta,
                                                     const double* __restrict__ omega,
                                                     const int64_t* __restrict__ idx, double* hs,
-                                                    double* newval, int32_t* touched, int pos0) {
+                                                    double* newval, int32_t* touched, int pos0,
+                                                    double* qs = nullptr /* sqrt-lasso: r'r after each visit */) {
     using R = GramRec<NG>;
     constexpr int B = R::B;
     const int lane = threadIdx.x;
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
     const double ia_me = 1.0 / a_me;
     const double thr_me = lambda0 * om_me * (n_total * ia_me);
     int dom = 0;
-    double v_me = 0.0, nv_me = 0.0, h_me = 0.0;
+    double v_me = 0.0, nv_me = 0.0, h_me = 0.0, q_me = 0.0;
     if (loss != 1 && !dup) {
         // least squares, no repeated coordinate (every scheduler-made pass): the chain is fma ->
         // soft-threshold -> subtract -> broadcast -> fma and nothing else.  Lanes outside the block
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
                 const double b_s = readlane_f64(b_me, s), a_s = readlane_f64(a_me, s);
                 q = q - 2.0 * h_s * b_s + h_s * h_s * a_s;
                 if (q < 0.0) q = 0.0;
+                if (lane == s) q_me = q;
             }
             if (dup) {
                 const int64_t k_s = (int64_t)readlane_u64((uint64_t)k_me, s);
@@ -535,6 +537,7 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
         newval[pos0 + lane] = nv_me;
         touched[pos0 + lane] = (loss == 1) ? 0 : ((v_me != 0.0) ? 1 : 0);
         if (last) beta[k_me] = nv_me;
+        if (qs && loss == 1) qs[pos0 + lane] = q_me;
     }
 }
 
@@ -543,144 +546,219 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
 // The Gram COLUMNS the gradient cache keeps for the coordinates that move (cdhip.hip, GradCache): with
 // G_j = X'X_j for every moved j, X_k'r is known for every k without reading X again.  Same use of the
 // matrix pipe as k_gramstep -- a 16 x 16 fp64 accumulator tile in 8 registers, rows of X as the K
-// dimension, lane (c, g) loading 16 bytes of column c at vector 4u + g -- with separate A and B operands
-// (4 x 2 tiles per wave).  Grid: blockIdx.x = lane of SUPER-groups (256 consecutive columns: one group of 64 per
-// wave; the block walks the super-groups x, x + gridDim.x, ... one after the other), blockIdx.y = row lane (the
-// block takes the row slabs y, y + gridDim.y, ... of 1024 vectors, 64 vectors at a time, all four waves on the
-// same chunk); a record per (column group, row lane), summed by k_cross_reduce.  X is streamed once
-// (non-temporal fragment loads); the block's B chunk -- 32 columns x 64 vectors -- is loaded once, fully
-// coalesced, into LDS (double-buffered: the next chunk's loads are in flight during this chunk's MFMAs) and read
-// from there by all four waves.
-// How it got here (cfg3: n = 2e6, p = 5000; per batch of 32 columns).  v1, one launch per column group with B
-// fragments loaded from HBM by every launch: 79 launches, 28 ms.  v2, one launch, B fragments re-read out of L2
-// by every column group (temporal loads): FETCH_SIZE 74 GB = X once, yet 22 .. 24 ms = 3.3 .. 3.6 TB/s of X at
-// 1e7 x 1000, 2e6 x 5000 and 5e5 x 20000 alike, MfmaUtil 39 %, MemUnitStalled 0, unmoved by tile counts, loads
-// in flight, occupancy, software pipelining or column groups in flight (tools/cross_scan.sh, cross_rate.py) --
-// but 18 ms with 16 B columns and 17 ms with 8: what bound it was the volume of loads through the CUs'
-// vector-memory path (~5 TB/s in total), a third of which were B fragments coming from L2.  Hence B through LDS:
-// 20 ms per batch = 4.0 TB/s of X, MfmaUtil 47 % (2 vector rows of fragment loads in flight: 1 gives 24.7 ms, 4
-// gives 21.4 ms; 1, 2 or 4 super-groups in flight alike, 8 slower).  What is left is the fragment-shaped A loads.
-// fp32 storage is widened to fp64 on the way in (an occasional pass, not the sweep).
-#ifndef CDH_CROSS_UH
-#define CDH_CROSS_UH 2
-#endif
-#ifndef CDH_CROSS_OCC
-#define CDH_CROSS_OCC 2
-#endif
+// dimension -- with separate A and B operands (4 x 2 tiles per wave).  Grid: blockIdx.x = lane of SUPER-groups
+// (256 consecutive columns: one group of 64 per wave; the block walks the super-groups x, x + gridDim.x, ... one
+// after the other), blockIdx.y = row lane (the block takes the row slabs y, y + gridDim.y, ... of 1024 vectors);
+// a record per (column group, row lane), summed by k_cross_reduce.  fp32 storage is widened to fp64 on the way
+// into the MFMA (an occasional pass, not the sweep).
+//
+// How it got here (n = 2e6, p = 5000, fp64: 80 GB; one batch of 32 columns; tools/cross_bench.hip holds the earlier
+// forms).  Round 2: fragment-shaped A loads straight from HBM -- a wave instruction takes 64 B from each of 16 columns,
+// so every 128-B line is asked for twice and each quarter-wave touches 16 different lines for 16 bytes apiece -- with
+// the B chunk through LDS: 19.3-21.3 ms = 3.8-4.1 TB/s of X.  Round 3: BOTH operands by LDS-DMA in whole lines:
+//   * one `global_load_lds_dwordx4` moves 8 columns x 8 vectors (8 whole 128-B lines) straight into LDS, no VGPRs on
+//     the way; an LDS-DMA writes lane l at (wave-uniform base) + 16 l, so the image cannot be padded: the bank
+//     conflicts of the MFMA-fragment reads are removed on the SOURCE side instead -- lane (column cl = l / 8, slot
+//     j = l % 8) fetches vector j ^ (cl & 6) of its line, i.e. vector v of column cc sits in slot 8 cc + (v ^ (cc & 6)),
+//     and the ds_read_b128 of lane (c, g) -- column 16 t + c, vector 4 u + g -- is conflict-free in each of the
+//     instruction's four lane groups (checked exhaustively in tests/test_abi_and_host.py);
+//   * a wave's unit of work is a HALF sub-chunk: 32 of its 64 A columns x 8 vectors (16 rows of fp64) = 4 pieces = 4 KB,
+//     in a ring of R slots; the block's B sub-chunk (32 columns x 8 vectors) is 4 pieces, ONE PER WAVE, shared by the
+//     four waves and riding along with the even halves; while slot s is multiplied the next R - 1 are in flight, and
+//     slot s + R is issued as soon as s has been read into registers;
+//   * the waits are COUNTED (`s_waitcnt vmcnt(N)`: the loads of the younger slots stay out) and, like the DMAs
+//     themselves, written in assembly -- hipcc drains every LDS-DMA it knows of (vmcnt(0)) ahead of an LDS read it
+//     cannot prove disjoint, which serialises load and matrix phases; it knows nothing of an asm load.  One block
+//     barrier per sub-chunk (the B pieces of all four waves have landed; everyone is done with the B buffer about to
+//     be refilled).
+// Measured (tools/cross_bench.hip, profiles/r3_cross_*): 15.3 ms with one sub-chunk in flight per wave and two
+// blocks per CU -- and the SAME with three slots in flight: not latency.  Loads alone take 13.0 ms (6.16 TB/s), the
+// matrix work alone 9.6 ms, each at 2.39 GHz; together the chip holds 1.84-1.87 GHz (in-kernel s_memtime /
+// s_memrealtime): the two pipes are paid for out of one power budget, so what helps is whatever lets the pass finish
+// in fewer joules -- non-temporal A loads (-3 %), a shallower ring at THREE blocks per CU (R = 2: 44 KB of LDS;
+// -6 %), priority for the short read / issue stretches over the partner waves' MFMA phases (-1 %):
+// 14.4 ms = 5.57 TB/s of X (0.70 of the 8 TB/s peak), fp32 storage 11.1 ms (matrix-bound: 10.3 ms of MFMA on 40 GB).
+// Rows past nvec inside a column are the zero pad (ld is a multiple of 32 elements = whole sub-chunks); columns past
+// p and B columns past nbc are clamped to valid ones and their results never read.  Observation weights
+// (G = X'WX, CDWeightedLSLoss): the weight of each row multiplies the B fragment on its way into the MFMA (a 128-byte
+// piece of w per sub-chunk, fetched by every wave to the same place so that all waves count the same loads).
 constexpr int kCrossTA = 4, kCrossTB = 2, kCrossA = 16 * kCrossTA, kCrossB = 16 * kCrossTB,
               kCrossRec = kCrossTA * kCrossTB * 256;
-constexpr int kCrossUH = CDH_CROSS_UH;   // vector rows of fragment loads in flight per group
 constexpr int kCrossSlab = 1024;         // vectors per row slab (fp64: 2048 rows)
-constexpr int kCrossXS = 64 + 2;          // LDS column stride of the B chunk in 16-byte slots (pad 2: conflict-free fragment reads)
-template <typename T>
-__global__ __launch_bounds__(64 * kGramWaves, CDH_CROSS_OCC) void k_cross(const T* __restrict__ X, int64_t ld, int64_t nvec,
-                                                                        int64_t p, const int64_t* __restrict__ bcols,
-                                                                        int nbc, double* __restrict__ partials) {
+constexpr int kCrossOcc = 3;             // blocks per CU of k_cross (its 44 KB of LDS and 151 registers allow three)
+constexpr int kX2SV = 8;                          // vectors per sub-chunk
+constexpr int kX2BSlots = kCrossB * kX2SV;        // 16-byte slots of the block's B sub-chunk
+constexpr int kX2SPS = kCrossSlab / kX2SV;        // sub-chunks per row slab
+template <int AUX>
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    const unsigned lds_dst_uniform = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);   // the "s" operand must be an SGPR
+    if constexpr (AUX == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_uniform(const void* p) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(const __attribute__((address_space(3))) void*)p);
+}
+template <typename T, bool HASW, int AUX_A = 2, int R = 2, int OCC = kCrossOcc, bool PRIO = true>
+__global__ __launch_bounds__(64 * kGramWaves, OCC) void k_cross(const T* __restrict__ X, int64_t ld, int64_t nvec, int64_t p,
+                                                               const int64_t* __restrict__ bcols, int nbc,
+                                                               const T* __restrict__ w, double* __restrict__ partials) {
     using V = typename VecOf<T>::V;
     constexpr int NV = VecOf<T>::N;
-    // the block's B chunk (32 columns x 64 vectors), double-buffered: loaded once per chunk, fully coalesced
-    // (a wave instruction = 64 consecutive vectors of one column), and shared by the four waves, each of which
-    // works on a DIFFERENT group of 64 X columns -- so the B fragments reach the matrix pipe through LDS and
-    // the vector-memory path carries (256 + 32) columns per 256 of X instead of (64 + 32) per 64
-    __shared__ V s_b[2][kCrossB * kCrossXS];
-    __shared__ double s_red[kGramWaves][256];
+    constexpr int HS = 32 * kX2SV;                    // 16-byte slots of one ring slot (32 columns x 8 vectors)
+    constexpr int EV = 5 + (HASW ? 1 : 0), OD = 4;    // DMA instructions a wave issues per even / odd ring slot
+    static_assert(R == 2 || R == 4 || R == 6, "ring depth");
+    constexpr int NB = R / 2 + 1;                     // B pieces in flight + the one being read
+    __shared__ V s_a[kGramWaves][R][HS];
+    __shared__ V s_b[NB][kX2BSlots];
+    __shared__ V s_w[HASW ? NB : 1][HASW ? kX2SV : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const V* bld[kCrossB / kGramWaves];       // this thread's share of the cooperative B load: columns wave, wave + 4, ...
-    bool bact[kCrossB / kGramWaves];
-#pragma unroll
-    for (int i = 0; i < kCrossB / kGramWaves; ++i) {
-        const int col = wave + kGramWaves * i;
-        bact[i] = col < nbc;
-        bld[i] = reinterpret_cast<const V*>(X + bcols[bact[i] ? col : 0] * ld);
-    }
+    const int cl = lane >> 3, sj = (lane & 7) ^ (cl & 6);
     const int64_t nslabs = (nvec + kCrossSlab - 1) / kCrossSlab;
     const int64_t ngroups = (p + kCrossA - 1) / kCrossA, nsuper = (ngroups + kGramWaves - 1) / kGramWaves;
-    constexpr int CPS = kCrossSlab / 64;      // chunks per slab
-    // chunk number q of this block's row lane -> first vector
-    auto chunk_v0 = [&](int64_t q) { return ((int64_t)blockIdx.y + (q / CPS) * gridDim.y) * kCrossSlab + (q % CPS) * 64; };
     const int64_t my_slabs = nslabs > blockIdx.y ? (nslabs - blockIdx.y + gridDim.y - 1) / gridDim.y : 0;
-    const int64_t nq = my_slabs * CPS;
-    auto load_b = [&](V (&regs)[kCrossB / kGramWaves], int64_t q) {
-        const int64_t v = chunk_v0(q) + lane;
+    // sub-chunks this block's row lane really has: only the very last slab of the column can be partial
+    int64_t nq = my_slabs * kX2SPS;
+    if (my_slabs > 0 && (int64_t)blockIdx.y + (my_slabs - 1) * gridDim.y == nslabs - 1)
+        nq -= kX2SPS - ((nvec - (nslabs - 1) * kCrossSlab) + kX2SV - 1) / kX2SV;
+    auto sub_v0 = [&](int64_t q) { return ((int64_t)blockIdx.y + (q / kX2SPS) * gridDim.y) * kCrossSlab + (q % kX2SPS) * kX2SV; };
+    const int bcol_i = 8 * wave + cl;
+    const V* bsrc = reinterpret_cast<const V*>(X + bcols[bcol_i < nbc ? bcol_i : 0] * ld) + sj;
+    const unsigned a_base = lds_addr_uniform(&s_a[wave][0][0]), b_base = lds_addr_uniform(&s_b[0][0]) + 1024u * (unsigned)wave,
+                   w_base = lds_addr_uniform(&s_w[0][0]);
+    int f_slot[2][2];                                  // fragment slots inside a ring slot / the B image: [tile][u]
 #pragma unroll
-        for (int i = 0; i < kCrossB / kGramWaves; ++i)
-            regs[i] = (bact[i] && v < nvec) ? ld_stream<false>(bld[i] + v) : vzero((V*)nullptr);
-    };
-    auto store_b = [&](const V (&regs)[kCrossB / kGramWaves], int buf) {
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int i = 0; i < kCrossB / kGramWaves; ++i) s_b[buf][(wave + kGramWaves * i) * kCrossXS + lane] = regs[i];
-    };
-    // only gridDim.x super-groups (4 column groups each, one per wave) are in flight at any time; the block walks
-    // its share of them one after the other, a record per (column group, row lane)
+        for (int u = 0; u < 2; ++u) f_slot[t][u] = (16 * t + c) * kX2SV + ((4 * u + g) ^ ((16 * t + c) & 6));
     for (int64_t sg = blockIdx.x; sg < nsuper; sg += gridDim.x) {
         const int64_t cg = sg * kGramWaves + wave;
         const int64_t a0 = cg * kCrossA;
-        const V* av[kCrossTA];
-        bool aact[kCrossTA];
+        const V* asrc[8];
 #pragma unroll
-        for (int grp = 0; grp < kCrossTA; ++grp) {
-            const int64_t col = a0 + 16 * grp + c;
-            aact[grp] = cg < ngroups && col < p;
-            av[grp] = reinterpret_cast<const V*>(X + (aact[grp] ? col : 0) * ld);
+        for (int i = 0; i < 8; ++i) {
+            int64_t col = a0 + 8 * i + cl;
+            if (col >= p) col = p - 1;
+            asrc[i] = reinterpret_cast<const V*>(X + col * ld) + sj;
         }
+        // half h of sub-chunk q -> ring slot (2 q + h) & 3; with the even halves, the block's B piece of the sub-chunk
+        auto issue = [&](int64_t q, int h) {
+            const int64_t v0 = sub_v0(q);
+            const unsigned dst = a_base + 4096u * (unsigned)((2 * q + h) % R);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16_asm<AUX_A>(asrc[4 * h + i] + v0, dst + 1024u * (unsigned)i);
+            if (h == 0) {
+                glds16_asm<0>(bsrc + v0, b_base + 4096u * (unsigned)(q % NB));
+                if constexpr (HASW) {
+                    // every wave fetches the same 128 bytes to the same place: the counted waits need one count per wave
+                    if (lane < kX2SV) glds16_asm<0>(reinterpret_cast<const V*>(w) + v0 + lane, w_base + 128u * (unsigned)(q % NB));
+                }
+            }
+        };
         dvec4 tile[kCrossTA * kCrossTB];
 #pragma unroll
         for (int t = 0; t < kCrossTA * kCrossTB; ++t) tile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
-        V breg[kCrossB / kGramWaves];
-        __syncthreads();                       // the previous super-group's last chunk has been consumed
-        if (nq > 0) { load_b(breg, 0); store_b(breg, 0); }
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < R / 2; ++j)
+            if (j < nq) { issue(j, 0); issue(j, 1); }
         for (int64_t q = 0; q < nq; ++q) {
-            const int buf = (int)(q & 1);
-            const int64_t v0 = chunk_v0(q);
-            if (q + 1 < nq) load_b(breg, q + 1);          // in flight while this chunk is multiplied
-            if (v0 < nvec) {
-#pragma unroll 1
-                for (int u0 = 0; u0 < 16; u0 += kCrossUH) {
-                    V xa[kCrossUH][kCrossTA], xb[kCrossUH][kCrossTB];
+            const int bq = (int)(q % NB);
+            V af[2][2], bf[2][kCrossTB], wf[2];
+            // ---- even half: this wave's slot 2q and B piece have landed (the three younger slots may still fly);
+            // the barrier: so have the other waves' B pieces, and everyone is done with B(q - 1) = the buffer of B(q + 2)
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+            // (loads per slot: even EV = 4 A pieces + the B piece (+ the weights' piece), odd OD = 4 A pieces)
+            if (q + R / 2 - 1 < nq) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(OD + (R / 2 - 1) * (EV + OD)) : "memory");   // younger: 2q+1 .. 2q+R-1
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(OD) : "memory");                          // at least 2q+1 is younger (a stricter wait is safe)
+            __builtin_amdgcn_s_barrier();
+            {
+                const V* ring = &s_a[wave][(2 * q) % R][0];
 #pragma unroll
-                    for (int u = 0; u < kCrossUH; ++u) {
-                        const int64_t v = v0 + 4 * (u0 + u) + g;
-                        const bool in = v < nvec;
+                for (int u = 0; u < 2; ++u) {
 #pragma unroll
-                        for (int grp = 0; grp < kCrossTA; ++grp)
-                            xa[u][grp] = (aact[grp] && in) ? ld_stream<true>(av[grp] + v) : vzero((V*)nullptr);
+                    for (int t = 0; t < 2; ++t) af[u][t] = ring[f_slot[t][u]];
 #pragma unroll
-                        for (int grp = 0; grp < kCrossTB; ++grp) xb[u][grp] = s_b[buf][(16 * grp + c) * kCrossXS + 4 * (u0 + u) + g];
-                    }
-#pragma unroll
-                    for (int u = 0; u < kCrossUH; ++u)
-#pragma unroll
-                        for (int e = 0; e < NV; ++e) {
-                            double b[kCrossTB];
-#pragma unroll
-                            for (int gb = 0; gb < kCrossTB; ++gb) b[gb] = (double)xb[u][gb][e];
-#pragma unroll
-                            for (int ga = 0; ga < kCrossTA; ++ga) {
-                                const double a = (double)xa[u][ga][e];
-#pragma unroll
-                                for (int gb = 0; gb < kCrossTB; ++gb)
-                                    tile[ga * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[gb], tile[ga * kCrossTB + gb], 0, 0, 0);
-                            }
-                        }
+                    for (int t = 0; t < kCrossTB; ++t) bf[u][t] = s_b[bq][f_slot[t][u]];
+                    if constexpr (HASW) wf[u] = s_w[bq][4 * u + g];
                 }
             }
-            if (q + 1 < nq) store_b(breg, buf ^ 1);
-            __syncthreads();                   // the next chunk is in LDS; this one has been read by every wave
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the reads have returned: the slot may be refilled
+            if (q + R / 2 < nq) issue(q + R / 2, 0);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            double b[2][NV][kCrossTB];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < NV; ++e)
+#pragma unroll
+                    for (int gb = 0; gb < kCrossTB; ++gb) {
+                        b[u][e][gb] = (double)bf[u][gb][e];
+                        if constexpr (HASW) b[u][e][gb] *= (double)wf[u][e];
+                    }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < NV; ++e)
+#pragma unroll
+                    for (int ga = 0; ga < 2; ++ga) {
+                        const double a = (double)af[u][ga][e];
+#pragma unroll
+                        for (int gb = 0; gb < kCrossTB; ++gb)
+                            tile[ga * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u][e][gb], tile[ga * kCrossTB + gb], 0, 0, 0);
+                    }
+            // ---- odd half: slot 2q + 1 (younger: 2q+2, 2q+3, and 2q+4, just issued) ----------------------------------
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+            if (q + R / 2 < nq) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((R / 2 - 1) * (EV + OD) + EV) : "memory");   // younger: 2q+2 .. 2q+R
+            else if (q + R / 2 - 1 < nq) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((R / 2 - 1) * (EV + OD)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {
+                const V* ring = &s_a[wave][(2 * q + 1) % R][0];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) af[u][t] = ring[f_slot[t][u]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (q + R / 2 < nq) issue(q + R / 2, 1);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < NV; ++e)
+#pragma unroll
+                    for (int ga = 0; ga < 2; ++ga) {
+                        const double a = (double)af[u][ga][e];
+#pragma unroll
+                        for (int gb = 0; gb < kCrossTB; ++gb)
+                            tile[(2 + ga) * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u][e][gb], tile[(2 + ga) * kCrossTB + gb], 0, 0, 0);
+                    }
         }
-        // this wave's record: its own column group (waves past the last group have nothing to write)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        double* s_red = reinterpret_cast<double*>(&s_a[wave][0][0]);      // R x 4 KB per wave
 #pragma unroll
         for (int t = 0; t < kCrossTA * kCrossTB; ++t) {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) s_red[wave][(g + 4 * q4) * 16 + c] = tile[t][q4];   // D[i = g + 4 q4][j = c]
+            for (int q4 = 0; q4 < 4; ++q4) s_red[(g + 4 * q4) * 16 + c] = tile[t][q4];   // D[i = g + 4 q4][j = c]
             __builtin_amdgcn_wave_barrier();
             if (cg < ngroups) {
                 double* __restrict__ out = partials + (cg * gridDim.y + blockIdx.y) * kCrossRec + t * 256;
 #pragma unroll
-                for (int v = lane; v < 256; v += 64) out[v] = s_red[wave][v];
+                for (int v = lane; v < 256; v += 64) out[v] = s_red[v];
             }
             __builtin_amdgcn_wave_barrier();
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 }
 // out[cg][v] = sum over the J row-slab records of column group cg, in a fixed order
@@ -725,6 +803,126 @@ __global__ __launch_bounds__(256) void k_cov_record(const double* __restrict__ g
     }
     for (int i = threadIdx.x; i < B; i += blockDim.x) rec[R::OFF_C + i] = (i < nb) ? g[s_k[i]] : 0.0;
     if (threadIdx.x == 0) rec[R::OFF_Q] = ctrl->q_carry;   // r'r (read by the sqrt-lasso update only): carried, never re-read from r
+}
+
+// ---- a whole full pass from the cache, on the device (grad_cache.hpp: gc_pass_device) ------------------------------
+// A visit of coordinate k is SETTLED when the exact visit would leave beta_k at zero and r untouched:
+//   beta_k == 0, a_k > 0 (a zero column goes to the exact path: the reference turns it into NaN) and
+//   |g_k| <= thr_k (1 - 1e-9) - cert_abs sqrt(a_k),   thr_k = lambda0 omega_k n   (sqrt-lasso: lambda0 omega_k ||r||).
+__device__ __forceinline__ bool cov_settled(double g, double a, double beta, double thr_base, double om, double cert_abs) {
+    return beta == 0.0 && a > 0.0 && fabs(g) <= thr_base * om * (1.0 - 1e-9) - cert_abs * sqrt(a);
+}
+struct CovScanOut { int32_t count, nzero, bad_pos, pad; };
+// One block: classifies the m positions of the pass against the gradient as it stands, compacts the UNSETTLED ones in
+// visit order (upos[j] = position, vis[j] = coordinate: the visit list of the covariance-form blocks that follow),
+// records for every coordinate its position and whether it was settled (the re-check below needs both), counts the
+// settled coordinates whose gradient is exactly zero (the host's SparseIterate bookkeeping differs for those: it then
+// takes the pass the slow way), and snapshots g and beta so that a pass whose re-check fails can be undone.
+__global__ __launch_bounds__(1024) void k_cov_scan(const double* __restrict__ g, const double* __restrict__ a,
+                                                   const double* __restrict__ beta, const double* __restrict__ omega,
+                                                   const Ctrl* ctrl, const int64_t* __restrict__ idx, int m, int64_t p,
+                                                   int32_t* __restrict__ pos_of, uint8_t* __restrict__ setflag,
+                                                   int32_t* __restrict__ upos, int64_t* __restrict__ vis,
+                                                   double* __restrict__ g_snap, double* __restrict__ beta_snap,
+                                                   CovScanOut* out) {
+    __shared__ int s_wcnt[16];
+    __shared__ int s_base, s_nzero;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int64_t k = tid; k < p; k += 1024) { g_snap[k] = g[k]; beta_snap[k] = beta[k]; pos_of[k] = -1; setflag[k] = 0; }
+    if (tid == 0) { s_base = 0; s_nzero = 0; }
+    const int loss = ctrl->loss, has_omega = ctrl->has_omega;
+    const double thr_base = ctrl->lambda0 * (loss == 1 ? sqrt(ctrl->q_carry) : ctrl->n_total), cert_abs = ctrl->cert_abs;
+    __syncthreads();
+    for (int i0 = 0; i0 < m; i0 += 1024) {
+        const int i = i0 + tid;
+        const bool valid = i < m;
+        const int64_t k = valid ? idx[i] : 0;
+        const double gk = g[k];
+        const bool st = valid && cov_settled(gk, a[k], beta[k], thr_base, has_omega ? omega[k] : 1.0, cert_abs);
+        const bool uns = valid && !st;
+        if (valid) { pos_of[k] = i; setflag[k] = st ? 1 : 0; }
+        if (st && gk == 0.0) atomicAdd(&s_nzero, 1);
+        const unsigned long long mask = __ballot(uns);
+        if (lane == 0) s_wcnt[wave] = __popcll(mask);
+        __syncthreads();
+        int before = s_base;
+        for (int wv = 0; wv < wave; ++wv) before += s_wcnt[wv];
+        if (uns) {
+            const int j = before + __popcll(mask & ((1ull << lane) - 1ull));
+            upos[j] = i; vis[j] = k;
+        }
+        __syncthreads();
+        if (tid == 0) { int tot = 0; for (int wv = 0; wv < 16; ++wv) tot += s_wcnt[wv]; s_base += tot; }
+        __syncthreads();
+    }
+    if (tid == 0) { out->count = s_base; out->nzero = s_nzero; out->bad_pos = 0x7fffffff; out->pad = 0; }
+}
+// beta and g back to the snapshot (a pass whose re-check failed never happened)
+__global__ __launch_bounds__(256) void k_cov_restore(double* __restrict__ g, double* __restrict__ beta,
+                                                     const double* __restrict__ g_snap, const double* __restrict__ beta_snap, int64_t p) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < p) { g[k] = g_snap[k]; beta[k] = beta_snap[k]; }
+}
+// k_cov_gupdate for a block of a device-side full pass: g -= sum_i h_i G_ki as before, and on the way the RE-CHECK of the
+// positions that were skipped as settled: coordinate k's certificate was read before this pass's moves, so it is tested
+// again against the gradient as it stands when its turn comes -- after the moves of the visits before position
+// pos_of[k], before those after it (sqrt-lasso: with ||r|| as it stands then, qs[] = r'r after each visit).  The block
+// answers for the skipped positions in (position of the previous block's last visit, position of its own last visit],
+// the last block of the pass also for those after its last visit.  A certificate that no longer holds is reported as
+// the smallest such position (out->bad_pos); the host then undoes the pass and walks it the careful way.
+__global__ __launch_bounds__(256) void k_cov_gupdate_chk(double* __restrict__ g, const double* __restrict__ Gcols,
+                                                         const int32_t* __restrict__ slot, const double* __restrict__ a,
+                                                         const double* __restrict__ omega, const Ctrl* ctrl, int64_t p,
+                                                         const int64_t* __restrict__ vis, const double* __restrict__ hs,
+                                                         const double* __restrict__ qs, const int32_t* __restrict__ upos,
+                                                         const int32_t* __restrict__ pos_of, const uint8_t* __restrict__ setflag,
+                                                         int j0, int nb, int m, int last_block, const double* __restrict__ q_start,
+                                                         CovScanOut* out) {
+    __shared__ double s_h[64], s_q[64];
+    __shared__ int64_t s_off[64];
+    __shared__ int s_pos[64];
+    __shared__ int s_n;
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        double h = 0.0, q = 0.0;
+        int64_t off = 0;
+        int pos = 0;
+        if (i < nb) { h = hs[j0 + i]; off = (int64_t)slot[vis[j0 + i]] * p; pos = upos[j0 + i]; q = qs[j0 + i]; }
+        const bool nz = (h != 0.0);
+        const unsigned long long mask = __ballot(nz);
+        if (nz) {
+            const int at = __popcll(mask & ((1ull << i) - 1ull));
+            s_h[at] = h; s_off[at] = off; s_pos[at] = pos; s_q[at] = q;
+        }
+        if (i == 0) s_n = __popcll(mask);
+    }
+    __syncthreads();
+    const int nmove = s_n;
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p) return;
+    const int p_prev = j0 > 0 ? upos[j0 - 1] : -1, p_last = last_block ? m - 1 : upos[j0 + nb - 1];
+    const int t = pos_of[k];
+    bool need = setflag[k] != 0 && t > p_prev && t <= p_last;
+    if (nmove == 0 && !need) return;
+    const int loss = ctrl->loss;
+    double acc = g[k], q_run = *q_start;
+    double cert_scale = 0.0, cert_off = 0.0;
+    if (need) {
+        cert_scale = ctrl->lambda0 * (ctrl->has_omega ? omega[k] : 1.0) * (1.0 - 1e-9);
+        cert_off = ctrl->cert_abs * sqrt(a[k]);
+    }
+    const double n_total = ctrl->n_total;
+    auto holds = [&](double gv, double qv) { return fabs(gv) <= cert_scale * (loss == 1 ? sqrt(qv) : n_total) - cert_off; };
+    for (int i = 0; i < nmove; ++i) {
+        if (need && s_pos[i] > t) {
+            if (!holds(acc, q_run)) atomicMin(&out->bad_pos, t);
+            need = false;
+        }
+        acc = fma(-s_h[i], Gcols[s_off[i] + k], acc);
+        q_run = s_q[i];
+    }
+    if (need && !holds(acc, q_run)) atomicMin(&out->bad_pos, t);
+    if (nmove) g[k] = acc;
 }
 
 __global__ void k_scatter_f64(double* __restrict__ dst, const int64_t* __restrict__ idx, const double* __restrict__ val, int m) {

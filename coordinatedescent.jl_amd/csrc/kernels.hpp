@@ -37,6 +37,8 @@ struct Ctrl {
     int32_t domain_error;
     int32_t pad;
     double q_carry;      // r'r carried from block to block by the covariance-form visits (sqrt-lasso)
+    double cert_abs;     // gradient-cache certificates: |g_k| <= thr_k (1 - 1e-9) - cert_abs sqrt(a_k); 0 for fp64 storage,
+                         // the rounding of an fp32 residual otherwise (cdhip.hip, gc_cert_abs)
 };
 
 // 16-byte native vectors (clang ext_vector_type: element access v[e] stays in registers and

@@ -195,7 +195,7 @@ int32_t cdh_set_reuse_residual(cdh_handle h, int32_t on);
  * are the same as visiting one by one.  on: 0 = never, 1 = full passes of the solves (default; cdh_pass
  * visits every column it is given), 2 = cdh_pass as well. */
 int32_t cdh_set_screening(cdh_handle h, int32_t on);
-/* Gradient cache of the screened full passes (exact; fp64 storage, no observation weights).  With the Gram
+/* Gradient cache of the screened full passes (exact; every loss, fp64 and fp32 storage).  With the Gram
  * columns X'X_j of the coordinates that move, X_k'r is known for every k without reading X, so a full pass
  * over a sparse iterate costs its real visits only -- what a lambda path (lasso.jl:250-252), the sigma loop
  * of scaledLasso! (:132-141) or a cold start's 51 solves (coordinate_descent.jl:32-36) repeat hundreds of
@@ -210,15 +210,16 @@ int32_t cdh_set_screening(cdh_handle h, int32_t on);
  * record the scalar-update kernel consumes -- X_k'r, the Gram entries between the block's coordinates -- is
  * read off the cached gradient and Gram columns ("covariance form"), and r is brought up to date once, before
  * anything reads it (cdh_get_residual, the moments, a streamed visit, ...).
- * cdh_cache_stats: out9 = {passes served, visits settled from the cache, visits made in those passes,
+ * cdh_cache_stats: out10 = {passes served, visits settled from the cache, visits made in those passes,
  * dots-only re-reference passes over X, Gram batches (up to 32 columns, one pass over X each),
- * Gram columns held, visits made in covariance form, residual catch-ups, covariance chunks rolled back
- * because a skipped coordinate's certificate did not survive the chunk's own moves}. */
+ * Gram columns held, visits made in covariance form, residual catch-ups, covariance chunks / passes rolled back
+ * because a skipped coordinate's certificate did not survive their own moves, passes served entirely on the
+ * device (scan, visits and certificate re-check without the gradient leaving HBM)}. */
 int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode);
 /* The mode the handle is in now (a path driver upgrades 1 -> 2 for its own duration and puts back what it found:
  * lasso.jl:250-252 runs on a caller's loss object, whose settings are the caller's). */
 int32_t cdh_get_gradient_cache(cdh_handle h, int32_t *out_mode);
-int32_t cdh_cache_stats(cdh_handle h, int64_t *out9);
+int32_t cdh_cache_stats(cdh_handle h, int64_t *out10);
 /* How far the carried gradient has been from X'r whenever it was taken afresh from X (after CDH_GC_REFRESH
  * covariance-form visits, or right now with rereference_now != 0: one dots-only pass over X):
  *   drift = max_k |g_carried[k] - X_k'r| / thr_k,   thr_k = lambda0 n omega_k (sqrt-lasso: lambda0 omega_k ||r||)

@@ -139,3 +139,25 @@ def test_every_export_rejects_a_null_handle():
     assert L.cdh_destroy(None) == cd._lib.CDH_OK
     assert L.cdh_device_count(None) == BAD and L.cdh_comm_unique_id(None) == BAD
     assert L.cdh_create(None, 0, 0, 8, 8, 0, 2, 0) == BAD
+
+
+def test_k_cross_lds_image_is_conflict_free_and_consistent():
+    """csrc/gram_kernels.hpp, k_cross: an LDS-DMA piece writes lane l at (wave-uniform base) + 16 l, so the image cannot
+    be padded; bank conflicts are removed on the SOURCE side -- lane (column cl = l // 8, slot j = l % 8) fetches vector
+    j ^ (cl & 6) of its 128-byte line, i.e. vector v of column cc sits in 16-byte slot 8 cc + (v ^ (cc & 6)).  Checked
+    here exhaustively: (a) the write side and the read side agree on where (column, vector) lives; (b) every
+    ds_read_b128 of the MFMA fragment pattern -- lane (c, g) reads column 16 t + c, vector 4 u + g -- hits 16 distinct
+    bank quads in each of the instruction's four lane groups (MI355X_MICROARCH.md, LDS table)."""
+    groups = [[*range(0, 4), *range(12, 16), *range(20, 28)], [*range(4, 12), *range(16, 20), *range(28, 32)],
+              [*range(32, 36), *range(44, 48), *range(52, 60)], [*range(36, 44), *range(48, 52), *range(60, 64)]]
+    slot = lambda cc, v: cc * 8 + (v ^ (cc & 6))        # noqa: E731  (f_slot / a_slot in the kernel)
+    for piece in range(8):                              # 8 pieces of 8 columns x 8 vectors: 64 columns
+        for lane in range(64):
+            cl, j = lane // 8, lane % 8
+            cc, v = 8 * piece + cl, j ^ (cl & 6)        # what the lane fetches (sj in the kernel)
+            assert slot(cc, v) == 64 * piece + lane     # ... lands where the fragment reads look for it
+    for t in range(4):
+        for u in range(2):
+            for grp in groups:
+                quads = {slot(16 * t + (lane & 15), 4 * u + (lane >> 4)) % 16 for lane in grp}
+                assert len(quads) == 16, (t, u, sorted(quads))
