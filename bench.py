@@ -169,8 +169,9 @@ def cfg1_cpu_vs_gpu(device=0):
     """BASELINE.json configs[0] run in full on both sides: lasso, n=1000, p=200, s=10,
     sigma=1, lambda=0.1, host-generated, ordered sweeps, optTol 1e-7 -- the reference's own CPU-runnable
     case.  CPU = the oracle's C restatement (kind "port", 1 thread); GPU = the same solve through the
-    C ABI, upload excluded (data resident, as for `value`) and included.  At this size one pass is 200
-    visits of 8 KB columns: the GPU side is launch-latency bound, and it is reported as it is."""
+    C ABI, upload excluded (data resident, as for `value`) and included.  At this size a streamed pass is 200
+    visits of 8 KB columns, i.e. launch latency and nothing else (round 2: 0.71 ms per solve); since round 3 such a
+    problem is solved in one launch on the resident Gram matrix (cdh_set_onchip_solve), reported as it is."""
     import numpy as np
     import coordinatedescent_jl_amd as cd
     import oracle as O
@@ -197,12 +198,17 @@ def cfg1_cpu_vs_gpu(device=0):
         cd.coordinateDescent_(xg, f, cd.ProxL1(lam), cd.CDOptions(**o))
     t_gpu = (time.perf_counter() - t0) / reps
     passes, visits = f.last_stats["passes"], f.last_stats["visits"]
+    onchip, last = f.onchip_stats(), f.onchip_last()
     f.close()
     return {"workload": "lasso_n1000_p200_s10_lambda0.1_full_solve", "cpu_port_ms": t_cpu * 1e3, "cpu_cores": 1,
             "gpu_ms": t_gpu * 1e3, "gpu_ms_incl_upload_and_create": (t_gpu + t_up) * 1e3,
             "passes": passes, "visits": visits, "cpu_passes": st["passes"],
             "cpu_coord_updates_per_sec": st["visits"] / t_cpu, "gpu_coord_updates_per_sec": visits / t_gpu,
-            "max_abs_beta_diff": float(np.max(np.abs(xg.dense() - xo.dense()))), "tolerance": 1e-10}
+            "max_abs_beta_diff": float(np.max(np.abs(xg.dense() - xo.dense()))), "tolerance": 1e-10,
+            # the GPU side is ONE launch per solve (csrc/small_solve.hpp): how many solves took it, and of the last one the
+            # kernel's own time, its visit steps and the clock the chip held for a one-wave kernel
+            "one_launch_solves": onchip["solves"], "solve_kernel_us": last["kernel_us"], "solve_kernel_steps": last["steps"],
+            "solve_kernel_clock_GHz": last["clock_GHz"]}
 
 
 def cfg3_path(device=0, n=2_000_000, p=5000, nlam=100):
@@ -232,8 +238,20 @@ def cfg3_path(device=0, n=2_000_000, p=5000, nlam=100):
             visits += f.last_stats["visits"]
         f._L.cdh_synchronize(f._h)
         dt = time.perf_counter() - t0
-        return {"workload": f"lasso_path_{nlam}_lambdas_n{n}_p{p}_f64_warm_started", "seconds": dt, "passes": passes,
-                "visits": visits, "visits_per_sec": visits / dt, "nnz_last": int(x.nnz), "gradient_cache": f.cache_stats()}
+        out = {"workload": f"lasso_path_{nlam}_lambdas_n{n}_p{p}_f64_warm_started", "seconds": dt, "passes": passes,
+               "visits": visits, "visits_per_sec": visits / dt, "nnz_last": int(x.nnz), "gradient_cache": f.cache_stats()}
+        # outside the timed region: what the path produced is CHECKED, not only timed.  (1) The cached gradient is taken
+        # afresh from X (one dots-only pass) and its drift from the carried one measured in units of the thresholds: the
+        # certificates' margin is 1e-9.  (2) The KKT conditions of the last lambda from X'r computed on the device:
+        # |X_k'r| / n = lambda omega_k on the support (to what optTol 1e-7 allows), <= it off the support.
+        out["cache_drift_over_threshold"] = f.cache_drift(rereference_now=True)
+        xtr = np.zeros(p)
+        cd._lib.check(f._L.cdh_xt_r(f._h, xtr.ctypes.data), f._h)
+        grad, thr, beta = np.abs(xtr) / n, lams[-1] * om, x.dense()
+        act = beta != 0
+        out["kkt_last_lambda"] = {"max_rel_violation_on_support": float(np.max(np.abs(grad[act] - thr[act]) / thr[act])) if act.any() else 0.0,
+                                  "max_ratio_off_support": float(np.max(grad[~act] / thr[~act])), "tolerance": "1e-5 / 1 + 1e-5 (optTol 1e-7)"}
+        return out
     finally:
         f.close()
 

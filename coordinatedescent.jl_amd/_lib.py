@@ -136,6 +136,9 @@ def lib():
         "cdh_set_gradient_cache": [vp, i32],
         "cdh_cache_stats": [vp, P(i64)],
         "cdh_get_gradient_cache": [vp, P(i32)],
+        "cdh_set_onchip_solve": [vp, i32],
+        "cdh_onchip_stats": [vp, P(i64)],
+        "cdh_onchip_last": [vp, P(i64)],
         "cdh_cache_drift": [vp, i32, P(f64)],
         "cdh_set_screening": [vp, i32],
         "cdh_comm_unique_id": [vp],

@@ -291,6 +291,21 @@ class _HipLoss(CoordinateDifferentiableFunction):
         """0 off, 1 rent-or-buy (default), 2 from the first full pass, 3 = 2 without the tall-problem guard."""
         check(self._L.cdh_set_gradient_cache(self._h, int(mode)), self._h)
 
+    def set_onchip_solve(self, on=True):
+        """One-launch solves of problems that fit on chip (cdh_set_onchip_solve; on by default)."""
+        check(self._L.cdh_set_onchip_solve(self._h, int(bool(on))), self._h)
+
+    def onchip_stats(self):
+        out = (C.c_int64 * 2)()
+        check(self._L.cdh_onchip_stats(self._h, out), self._h)
+        return {"solves": int(out[0]), "gram_matrices": int(out[1])}
+
+    def onchip_last(self):
+        """Of the last one-launch solve: visit steps, kernel time in microseconds, the clock (GHz) the chip held."""
+        out = (C.c_int64 * 3)()
+        check(self._L.cdh_onchip_last(self._h, out), self._h)
+        return {"steps": int(out[0]), "kernel_us": out[2] / 100.0, "clock_GHz": (out[1] / out[2] * 0.1) if out[2] else 0.0}
+
     def gradient_cache_mode(self):
         out = C.c_int32()
         check(self._L.cdh_get_gradient_cache(self._h, C.byref(out)), self._h)

@@ -130,6 +130,45 @@ struct GradCache {
             n_reconcile = 0;
 };
 
+// The one-launch solve of problems that fit on chip (small_solve.hpp): the full Gram matrix of the resident X, the
+// control block of the solve kernel, pinned staging for what comes back.
+constexpr int kSmallMaxP = 1024;
+constexpr int kSmallMaxLam = 64;                 // solves per launch (a cold start's numSteps + 1 = 51 by default)
+constexpr size_t kSmallMaxBytes = (size_t)16 << 20;
+
+struct SmallCtl {
+    double lambdas[kSmallMaxLam];
+    int32_t nlam, randomize, loss, has_omega;
+    int64_t maxIter;
+    double optTol, n_total;
+    uint64_t rng;                // splitmix64 state of the substitute RandomIterator: in / out
+    int32_t nnz_in, g_from_c;   // g_from_c: `ga` holds (X'y, a) and g = X'y - G beta is formed in the kernel; else ga holds (X'r, a)
+    // out
+    int64_t passes, full_passes, visits;
+    int32_t converged, domain_error;
+    double maxH;
+    int32_t nnz, pad1;
+    int64_t steps;               // visit steps taken (each settles a run of positions and makes at most one move)
+    uint64_t cycles, ticks;      // shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) the kernel ran for
+};
+
+struct SmallPath {
+    bool enabled = true;             // env CDH_SMALL_PATH (default 1), cdh_set_small_path
+    bool G_valid = false;
+    double* d_G = nullptr;           // p x p
+    char *d_io = nullptr, *h_io = nullptr;    // [SmallCtl][support][beta]: what crosses the bus per solve, one block each way
+    SmallCtl *d_ctl = nullptr, *h_ctl = nullptr;   // views into d_io / h_io (pinned)
+    int32_t *d_sup = nullptr, *h_sup = nullptr;
+    double *d_beta = nullptr, *h_beta = nullptr;
+    int64_t n_solves = 0, n_gram = 0;
+    bool c_valid = false;            // d_ca / h_c / yy hold X'y (X'Wy), diag(G) and y'y of the current y
+    double* d_ca = nullptr;          // interleaved (c_k, a_k), then y'y at [2p]
+    std::vector<double> h_c;         // host copy of c (lambda_max of a cold start needs no device work)
+    double yy = 0.0;
+    int ncache = 0;                  // Gram columns the solve kernel can keep in LDS
+    unsigned lds_bytes = 0;
+};
+
 struct cdh_handle_s {
     int dtype = CDH_F64, loss = CDH_LS, device = 0;
     int64_t n = 0, n_total = 0, row0 = 0, p = 0, ld = 0, nvec = 0;
@@ -162,6 +201,12 @@ struct cdh_handle_s {
     int screening = 1;            // 0 never, 1 the solves' full passes over sparse iterates, 2 cdh_pass too
     bool reuse_residual = false;  // warm starts skip initialize! when r is known to match beta
     bool r_consistent = false;    // r == y - X beta (up to rounding) for the handle's current iterate
+    // The one-launch solve never touches r: afterwards the residual on the device is STALE and stands for
+    // y - X * x_lazy, rebuilt (one k_init_resid launch) by sync_r when something asks for r -- a residual nobody reads
+    // is never formed.  x_lazy is the iterate that residual belongs to: the solve's result, and still that after the
+    // caller loads another iterate without initialize! (cdh_set_iterate leaves r alone, as the reference's x[k] = ... does).
+    bool r_lazy = false;
+    cdh::SupportList x_lazy;
     int64_t r_roundings = 0;      // launches that have rewritten r (each rounds it to the storage type once) since it was last rebuilt
     bool chunk_dup = false;       // the current chunk's visit list repeats a coordinate
     std::vector<int32_t> stamp;   // duplicate detection scratch, size p
@@ -198,6 +243,7 @@ struct cdh_handle_s {
     int64_t n_rccl_calls = 0, n_p2p_calls = 0, n_host_calls = 0;
     // profile
     GradCache gc;
+    SmallPath small;
     // beta changes the covariance-form visits have made that r has not seen yet: r_actual = r_virtual + X * pending
     std::vector<double> r_pending;
     std::vector<int64_t> r_pending_list;
@@ -349,7 +395,12 @@ int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
 // download (cdh_get_residual) -- and before X itself changes; nothing else needs r, so a warm-started path
 // whose solves all run from the cache pays for one catch-up when its caller finally asks for the residual
 // (moves of the same coordinate merge in the meantime).
+int32_t rebuild_residual_from(cdh_handle h, const cdh::SupportList& x, bool upload_beta);
 int32_t sync_r(cdh_handle h) {
+    if (h->r_lazy) {                  // r = y - X * x_lazy, now that somebody wants it (beta on the device mirrors h->x: left alone)
+        h->r_lazy = false;
+        return rebuild_residual_from(h, h->x_lazy, false);
+    }
     if (h->r_pending_list.empty()) return CDH_OK;
     std::vector<int64_t>& L = h->r_pending_list;
     for (size_t o = 0; o < L.size(); o += 64) {
@@ -454,12 +505,12 @@ void gc_invalidate(cdh_handle h, bool columns) {
 }
 // r was just set to y - X * (the handle's iterate) by a kernel: beta_ref follows; what changed against the
 // previous reference becomes pending moves (a warm start from another x is a move like any other)
-void gc_after_rebuild(cdh_handle h) {
+void gc_after_rebuild(cdh_handle h, const cdh::SupportList& x) {
     GradCache& c = h->gc;
     if (c.beta_ref.empty()) return;   // cache never sized (not applicable so far)
     if (c.valid && !c.beta_ok) gc_invalidate(h, false);
     std::vector<double> nb((size_t)h->p, 0.0);
-    for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) nb[(size_t)h->x.coord(s_)] = h->x.slot_value(s_);
+    for (int64_t s_ = 0; s_ < x.nnz(); ++s_) nb[(size_t)x.coord(s_)] = x.slot_value(s_);
     if (c.valid) {
         for (int64_t k = 0; k < h->p; ++k) {
             const double d = nb[(size_t)k] - c.beta_ref[(size_t)k];
@@ -492,27 +543,29 @@ void gc_note_moves(cdh_handle h, const int64_t* idx0, int m) {
 }
 
 // ---- initialize!: upload support, r = y - X beta ------------------------------------
-int32_t rebuild_residual(cdh_handle h) {
+int32_t rebuild_residual_from(cdh_handle h, const cdh::SupportList& x, bool upload_beta) {
     drop_r_pending(h);
+    h->r_lazy = false;
     h->r_roundings = 1;               // r = y - X beta, summed in fp64 and rounded once
-    const int64_t nnz = h->x.nnz();
+    const int64_t nnz = x.nnz();
     if (nnz == 0) {   // the cold start: beta = 0, r = y; nothing host-side is in flight, so no wait either
-        HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
+        if (upload_beta) HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->r, h->y, (size_t)h->ld * h->esz, hipMemcpyDeviceToDevice, h->stream));
         h->r_consistent = true;
-        gc_after_rebuild(h);
+        gc_after_rebuild(h, x);
         return CDH_OK;
     }
-    std::vector<double> dense((size_t)h->p, 0.0);
-    for (int64_t s = 0; s < nnz; ++s) dense[(size_t)h->x.coord(s)] = h->x.slot_value(s);
-    HIPCHK(h, hipMemcpyAsync(h->beta, dense.data(), sizeof(double) * h->p, hipMemcpyHostToDevice, h->stream));
-    std::vector<int64_t> si((size_t)std::max<int64_t>(nnz, 1));
-    std::vector<double> sv((size_t)std::max<int64_t>(nnz, 1));
-    for (int64_t s = 0; s < nnz; ++s) { si[(size_t)s] = h->x.coord(s); sv[(size_t)s] = h->x.slot_value(s); }
-    if (nnz > 0) {
-        HIPCHK(h, hipMemcpyAsync(h->d_sup_idx, si.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_sup_val, sv.data(), sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
+    if (upload_beta) {
+        std::vector<double> dense((size_t)h->p, 0.0);
+        for (int64_t s = 0; s < nnz; ++s) dense[(size_t)x.coord(s)] = x.slot_value(s);
+        HIPCHK(h, hipMemcpyAsync(h->beta, dense.data(), sizeof(double) * h->p, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // `dense` goes out of scope
     }
+    std::vector<int64_t> si((size_t)nnz);
+    std::vector<double> sv((size_t)nnz);
+    for (int64_t s = 0; s < nnz; ++s) { si[(size_t)s] = x.coord(s); sv[(size_t)s] = x.slot_value(s); }
+    HIPCHK(h, hipMemcpyAsync(h->d_sup_idx, si.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_sup_val, sv.data(), sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (h->nvec + kBlock - 1) / kBlock));
     CHK(dispatch(h, [&](auto* t) {
         using T = std::remove_pointer_t<decltype(t)>;
@@ -523,9 +576,10 @@ int32_t rebuild_residual(cdh_handle h) {
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors above go out of scope
     h->r_consistent = true;
-    gc_after_rebuild(h);
+    gc_after_rebuild(h, x);
     return CDH_OK;
 }
+int32_t rebuild_residual(cdh_handle h) { return rebuild_residual_from(h, h->x, true); }
 
 // does any coordinate repeat in the chunk?  (scheduler-made lists never do; caller-made ones may)
 void note_duplicates(cdh_handle h, const int64_t* idx0, int m) {
@@ -790,6 +844,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
 }
 
 #include "grad_cache.hpp"   // gc_size, gc_validate, gc_fetch, gc_fold, gc_full_pass
+#include "small_solve.hpp"  // small_applicable, small_prepare, small_solve
 
 // _cdPass! (coordinate_descent.jl:94-110)
 // Screening of a FULL pass (exact, no reference counterpart).  A visit of a coordinate with
@@ -941,6 +996,10 @@ void free_all(cdh_handle h) {
     if (h->gc.d_G) (void)hipFree(h->gc.d_G);
     if (h->gc.d_slot) (void)hipFree(h->gc.d_slot);
     if (h->gc.h_g_pin) (void)hipHostFree(h->gc.h_g_pin);
+    if (h->small.d_G) (void)hipFree(h->small.d_G);
+    if (h->small.d_io) (void)hipFree(h->small.d_io);
+    if (h->small.d_ca) (void)hipFree(h->small.d_ca);
+    if (h->small.h_io) (void)hipHostFree(h->small.h_io);
     {
         GradCache& c = h->gc;
         void* dv[] = {c.d_a, c.d_g_snap, c.d_beta_snap, c.d_qs, c.d_pass_idx, c.d_pos_of, c.d_upos, c.d_setflag, c.d_scan};
@@ -1017,6 +1076,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->ks = env_int("CDH_KS", 0);
         h->gc.mode = std::max(0, std::min(3, env_int("CDH_GRADIENT_CACHE", 1)));
         h->gc.cov = env_int("CDH_GC_COV", 1) != 0;
+        h->small.enabled = env_int("CDH_SMALL_PATH", 1) != 0;
         h->gc.refresh_after = std::max(1, env_int("CDH_GC_REFRESH", (int)kGcCovRefresh));
         const int step_per_cu = std::max(1, env_int("CDH_STEP_GRID_PER_CU", 8));
         const int block_per_cu = std::max(1, std::min(kBlockGridPerCU, env_int("CDH_BLOCK_GRID_PER_CU", 3)));
@@ -1095,12 +1155,13 @@ int32_t cdh_synchronize(cdh_handle h) {
 int32_t cdh_set_X_cols(cdh_handle h, int64_t j0, int64_t ncols, const void* host, int64_t ld) {
     NEED_H(h);
     if (ncols > 0) NEED_P(h, host);
-    if (!h->r_pending_list.empty()) {   // r still owes updates in terms of the OLD columns
+    if (!h->r_pending_list.empty() || h->r_lazy) {   // r still owes updates (or its rebuild) in terms of the OLD columns
         HIPCHK(h, hipSetDevice(h->device));
         CHK(sync_r(h));
     }
     h->r_consistent = false;
     gc_invalidate(h, true);
+    h->small.G_valid = false; h->small.c_valid = false;
     if (j0 < 0 || ncols < 0 || j0 + ncols > h->p || ld < h->n) return fail(h, CDH_DIM_MISMATCH, "column block outside X");
     if (ncols == 0) return CDH_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1130,7 +1191,9 @@ int32_t cdh_set_y(cdh_handle h, const void* host_y) {
     h->r_consistent = false;
     gc_invalidate(h, false);
     h->gc.yy_ok = false;
+    h->small.c_valid = false;
     drop_r_pending(h);                 // r = copy(y) below
+    h->r_lazy = false;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(h->y, host_y, (size_t)h->n * h->esz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->r, h->y, (size_t)h->n * h->esz, hipMemcpyDeviceToDevice, h->stream));
@@ -1161,6 +1224,7 @@ int32_t cdh_set_obs_weights(cdh_handle h, const void* host_w) {
     NEED_P(h, host_w);
     h->r_consistent = false;
     gc_invalidate(h, true);
+    h->small.G_valid = false; h->small.c_valid = false;
     if (h->loss != CDH_WLS) return fail(h, CDH_BAD_ARG, "observation weights need the CDH_WLS loss");
     HIPCHK(h, hipSetDevice(h->device));
     CHK(ensure_weights_buffer(h));
@@ -1178,6 +1242,7 @@ int32_t cdh_set_loss(cdh_handle h, int32_t loss) {
     if (loss == CDH_WLS) CHK(ensure_weights_buffer(h));
     h->loss = loss;
     h->ctrl.loss = loss;          // goes to the device with the next chunk's control block
+    if (h->has_w) { h->small.G_valid = false; h->small.c_valid = false; gc_invalidate(h, true); }   // X'WX is not X'X
     h->has_w = false;             // a weighted loss gets its weights from cdh_set_obs_weights
     h->r_consistent = false;
     gc_invalidate(h, false);
@@ -1189,7 +1254,9 @@ static int32_t cdh_generate_impl(cdh_handle h, uint64_t seed, int64_t s, double 
     if (s < 0 || s > h->p) return fail(h, CDH_BAD_ARG, "need 0 <= s <= p");
     gc_invalidate(h, true);
     h->gc.yy_ok = false;
+    h->small.G_valid = false; h->small.c_valid = false;
     drop_r_pending(h);
+    h->r_lazy = false;
     HIPCHK(h, hipSetDevice(h->device));
     // planted coefficients: beta*_j = z_j (1 + u_j) (benchmark/cd_bench.jl:14), stream 2
     std::vector<double> bstar((size_t)std::max<int64_t>(s, 1), 0.0);
@@ -1346,6 +1413,16 @@ static int32_t cdh_solve_impl(cdh_handle h, const cdh_options* opt, cdh_stats* o
     NEED_P(h, opt);
     HIPCHK(h, hipSetDevice(h->device));
     cdh_stats st{};
+    if (small_applicable(h, opt)) {
+        CHK(small_prepare(h));
+        if (h->small.enabled) {     // (the preparation may find no room and switch the path off)
+            uint64_t rng = opt->seed;
+            const double lam = h->ctrl.lambda0;
+            int32_t rcs = small_solve(h, opt, &lam, 1, &rng, &st, false);
+            if (out) *out = st;
+            return rcs;
+        }
+    }
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
     int32_t rc = solve(h, opt, sched, &st);
     if (out) *out = st;
@@ -1359,11 +1436,39 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
     h->domain_error = false;
     int32_t rc = CDH_OK;
-    if (opt->warmStart) {
+    bool small = small_applicable(h, opt);
+    if (small) { CHK(small_prepare(h)); small = h->small.enabled; }
+    uint64_t rng = opt->seed;       // the one-launch solve carries the scheduler's generator state itself
+    if (opt->warmStart && small) {
+        // initialize!(f, x) (:21) makes r = y - X x by definition: the one-launch solve derives its gradient from that
+        // identity (g = X'y - G x) and leaves the residual to be formed when somebody reads it
+        const double lam = h->ctrl.lambda0;
+        rc = small_solve(h, opt, &lam, 1, &rng, &st, true);
+    } else if (opt->warmStart) {
         // initialize!(f, x) (:21).  Optional shortcut for warm-started paths (LassoPath): the
         // carried residual already equals y - X beta, so the rebuild only re-rounds it.
         if (!(h->reuse_residual && h->r_consistent)) CHK(rebuild_residual(h));
         rc = solve(h, opt, sched, &st);
+    } else if (small) {
+        const double target = h->ctrl.lambda0;
+        h->x.clear();                                   // fill!(x, 0)           (:25)
+        HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
+        // _findLambdaMax (:29) at r = y: max_k |X_k'y| / n / omega_k (sqrt-lasso: / ||y||) -- from the cached X'y
+        double lmax = 0.0;
+        const double denom = h->loss == CDH_SQRT ? std::sqrt(h->small.yy) : (double)h->n_total;
+        for (int64_t k = 0; k < h->p; ++k) {
+            double t = std::fabs(-h->small.h_c[(size_t)(2 * k)] / denom);
+            if (h->has_omega) t /= h->h_omega[(size_t)k];
+            if (t > lmax) lmax = t;
+        }
+        st.lambda_max = lmax;
+        const double l1 = std::log(lmax), l2 = std::log(target);
+        const double step = (l2 - l1) / (double)opt->numSteps;
+        if (step == 0.0 || step != step)
+            return fail(h, CDH_BAD_ARG, "cold start: the range log(lambda_max):step:log(lambda0) has a zero step");
+        std::vector<double> grid((size_t)opt->numSteps + 1);   // the numSteps + 1 solves of (:32-36) inside one launch
+        for (int64_t j = 0; j <= opt->numSteps; ++j) grid[(size_t)j] = std::exp((j == opt->numSteps) ? l2 : l1 + (double)j * step);
+        rc = small_solve(h, opt, grid.data(), (int)grid.size(), &rng, &st, true);
     } else {
         const double target = h->ctrl.lambda0;          // g itself is never mutated by the reference:
         rc = [&]() -> int32_t {                         // whatever happens below, lambda0 is put back
@@ -1538,6 +1643,27 @@ int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode) {
     if (mode == 0) gc_invalidate(h, true);
     h->gc.mode = mode;
     h->gc.cooldown = 0; h->gc.backoff = 1;
+    return CDH_OK;
+}
+
+int32_t cdh_set_onchip_solve(cdh_handle h, int32_t on) {
+    NEED_H(h);
+    h->small.enabled = on != 0;
+    return CDH_OK;
+}
+
+int32_t cdh_onchip_stats(cdh_handle h, int64_t* out2) {
+    NEED_H(h);
+    NEED_P(h, out2);
+    out2[0] = h->small.n_solves; out2[1] = h->small.n_gram;
+    return CDH_OK;
+}
+
+int32_t cdh_onchip_last(cdh_handle h, int64_t* out3) {
+    NEED_H(h);
+    NEED_P(h, out3);
+    out3[0] = out3[1] = out3[2] = 0;
+    if (h->small.h_ctl) { out3[0] = h->small.h_ctl->steps; out3[1] = (int64_t)h->small.h_ctl->cycles; out3[2] = (int64_t)h->small.h_ctl->ticks; }
     return CDH_OK;
 }
 

@@ -1,0 +1,456 @@
+// small_solve.hpp -- the whole of _coordinateDescent! (coordinate_descent.jl:65-92) in ONE launch, for problems whose
+// design matrix is a few MB: a section of cdhip.hip kept in its own file (included once, inside cdhip.hip's anonymous
+// namespace, after grad_cache.hpp, whose Gram-column scratch it borrows).
+//
+// Why: the reference's own test and benchmark shapes are n <= 3000 (test/lasso.jl:76-101, benchmark/cd_bench.jl:8-14).
+// There a column is 8-24 KB and a pass of the streamed sweep is launch latency and nothing else: BASELINE.json's cfg1
+// (n = 1000, p = 200) took 0.71 ms per solve in round 2 -- 8 passes x ~21 launches -- against 0.10 ms for ONE CPU core.
+//
+// How: for p <= 1024 and n p sz <= 16 MB the handle keeps the full Gram matrix G = X'X (X'WX with observation weights)
+// in HBM -- p / 32 launches of k_cross, once per X -- and a solve is: one dots pass for g = X'r (k_col_dots, which the
+// warm start needs anyway), then ONE wave runs the reference's state machine on (g, G): pass after pass, full or active,
+// ordered or shuffled (the documented splitmix64 substitute, sparse_iterate.hpp), the visits in covariance form
+//   b = g_k,  beta_k <- S(beta_k + b / a_k, lambda n omega_k / a_k)   (sqrt-lasso: the closed form on (b, a_k, r'r)),
+//   g <- g - h G_k,   r'r <- r'r - 2 h b + h^2 a_k,
+// with ProximalBase's SparseIterate bookkeeping (support in order of first becoming non-zero, zeros kept until
+// dropzeros!'s swap-with-last) replayed on the device by lane 0, because the ORDER of the support is the visit order of
+// the next active pass.  The 51 solves of a cold start (coordinate_descent.jl:24-37) run inside the same launch.
+// One host round trip per solve: beta, the support and the statistics come back; the residual learns of the moves
+// through the same deferred catch-up as the gradient cache's covariance-form visits (sync_r).
+// A visit step evaluates 64 consecutive positions of the visit list at once against the current g: every position
+// before the first one that moves is settled exactly (g does not change until something moves), so a full pass over a
+// sparse iterate is a handful of steps, and an active pass is one step per visit.
+// Same iterates as the streamed sweeps up to the rounding of the g recurrence (tests: beta within 1e-10 of the oracle,
+// same pass counts and support order as its per-coordinate sweep).
+#pragma once
+
+// (SmallCtl and the size limits are declared next to the handle in cdhip.hip)
+
+// x mod d for d <= 65536 without a 64-bit division: (hi 2^32 + lo) mod d from three 32-bit remainders
+__device__ __forceinline__ uint32_t mod64_small(uint64_t x, uint32_t d) {
+    const uint32_t hi = (uint32_t)(x >> 32) % d, lo = (uint32_t)x % d;
+    const uint32_t t = (0xffffffffu % d + 1u) % d;          // 2^32 mod d
+    return (hi * t + lo) % d;                               // hi, t < 2^16: no overflow
+}
+__device__ __forceinline__ uint64_t small_rng_next(uint64_t& state) {
+    uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// One wave.  ga: interleaved (g_k, a_k) as k_col_dots leaves them; G: p x p, column k at G + k p; q_in: r'r (sqrt-lasso).
+// Dynamic LDS: the p-sized state (g, beta, a, omega; the visit list, the support's slots, the shuffle) and then as many
+// Gram COLUMNS as fit (ncache): a coordinate's column is kept from its first move on, so the active passes -- one step
+// per visit, the bulk of a solve -- never leave the chip.  What was slow in the first version of this kernel and is
+// gone: four dependent global loads per move (now all issued at once, or none), and three walks by lane 0 alone -- the
+// slots appended by the settled visits of a step, dropzeros!, the generator of the shuffle -- now done by the wave
+// (ballot-ranked appends; the swap-with-last compaction as a parallel hole / filler match; splitmix64 is a counter, so
+// its draws are independent).  Only Fisher-Yates' swaps themselves stay serial.
+// (A lone wave issues about one instruction per four cycles, so a step costs what it has instructions: the sqrt-lasso
+// closed form is compiled into its own kernel, and the loops over a p-vector are unrolled NP = 4 / 8 / 16 times for
+// p <= 256 / 512 / 1024 -- unrolled 16 times with a predicate per trip they alone were 1300 cycles of a step at p = 200.)
+template <bool SQRT, int NP>
+__global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int ncache, const double* __restrict__ ga,
+                                                    const double* __restrict__ G, const double* __restrict__ omega,
+                                                    const double* __restrict__ q_in, double* __restrict__ beta,
+                                                    int32_t* __restrict__ sup /* slot2ind, in / out */,
+                                                    double* __restrict__ beta_out /* a copy of beta next to ctl and sup: one copy back */) {
+    extern __shared__ double s_dyn[];
+    double* s_g = s_dyn;
+    double* s_beta = s_g + p;
+    double* s_a = s_beta + p;
+    double* s_om = s_a + p;
+    double* s_cols = s_om + p;                                   // ncache columns of p doubles
+    int32_t* s_list = reinterpret_cast<int32_t*>(s_cols + (size_t)ncache * p);
+    int32_t* s_slot2ind = s_list + p;
+    int32_t* s_ind2slot = s_slot2ind + p;
+    int32_t* s_order = s_ind2slot + p;                           // the shuffle; between passes: scratch of dropzeros!
+    int32_t* s_draw = s_order + p;
+    int32_t* s_colslot = s_draw + p;                             // coordinate -> cached column, -1 = none
+    const int lane = threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int has_omega = ctl->has_omega, randomize = ctl->randomize, nlam = ctl->nlam;
+    const double n_total = ctl->n_total, optTol = ctl->optTol;
+    const int64_t maxIter = ctl->maxIter;
+    uint64_t rng = ctl->rng;
+    int nnz = ctl->nnz_in, ncached = 0;
+    for (int k = lane; k < p; k += 64) {
+        s_g[k] = ga[2 * k]; s_a[k] = ga[2 * k + 1]; s_beta[k] = beta[k];
+        s_om[k] = has_omega ? omega[k] : 1.0;
+        s_ind2slot[k] = 0; s_colslot[k] = -1;
+    }
+    __syncthreads();
+    for (int s = lane; s < nnz; s += 64) { const int k = sup[s]; s_slot2ind[s] = k; s_ind2slot[k] = s + 1; }
+    double q = SQRT ? *q_in : 0.0;
+    if (ctl->g_from_c) {
+        // `ga` held c = X'y (X'Wy), q_in y'y: the gradient and r'r of the iterate follow from the Gram matrix alone,
+        //   g = c - G beta,   r'r = y'y - 2 beta'c + beta'G beta = y'y - sum_s beta_s (c_s + g_s)
+        // -- no pass over X or r at all (a warm start from beta = 0 is g = c)
+        __syncthreads();
+        for (int s = 0; s < nnz; ++s) {
+            const int ks = s_slot2ind[s];
+            const double bs = s_beta[ks];
+            const double* __restrict__ col = G + (int64_t)ks * p;
+            for (int j = lane; j < p; j += 64) s_g[j] = fma(-bs, col[j], s_g[j]);
+        }
+        __syncthreads();
+        if constexpr (SQRT) {
+            double acc = 0.0;
+            for (int s = lane; s < nnz; s += 64) { const int ks = s_slot2ind[s]; acc += s_beta[ks] * (ga[2 * ks] + s_g[ks]); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            q = *q_in - acc;
+            if (q < 0.0) q = 0.0;
+        }
+    }
+    const uint64_t t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
+    int64_t passes = 0, full_passes = 0, visits = 0, steps = 0;
+    int converged = 0, dom_any = 0;
+    double lastH = 0.0;
+    __syncthreads();
+    for (int il = 0; il < nlam; ++il) {
+        const double lambda0 = ctl->lambdas[il];
+        bool prev_conv = false, conv = true;
+        converged = 0;
+        for (int64_t iter = 0; iter < maxIter; ++iter) {
+            const bool full = conv;
+            const int L = full ? p : nnz;
+            // ---- reset!(it, full) + collect(it) (atom_iterator.jl:34-37, 53-64) ----
+            if (randomize) {
+                // Fisher-Yates, j_i = i + next() mod (L - i).  splitmix64's state is a counter: draw i is a function of
+                // state + (i + 1) gamma alone, so the draws are made by all lanes; only the swaps are sequential
+                for (int i = lane; i < L; i += 64) {
+                    s_order[i] = i;
+                    if (i + 1 < L) {
+                        uint64_t st = rng + (uint64_t)i * 0x9E3779B97F4A7C15ull;
+                        s_draw[i] = i + (int)mod64_small(small_rng_next(st), (uint32_t)(L - i));
+                    }
+                }
+                if (L > 1) rng += (uint64_t)(L - 1) * 0x9E3779B97F4A7C15ull;
+                __syncthreads();
+                if (lane == 0)
+                    for (int i = 0; i + 1 < L; ++i) {
+                        const int j = s_draw[i];
+                        const int t = s_order[i]; s_order[i] = s_order[j]; s_order[j] = t;
+                    }
+                __syncthreads();
+                for (int i = lane; i < L; i += 64) s_list[i] = full ? s_order[i] : s_slot2ind[s_order[i]];
+            } else {
+                for (int i = lane; i < L; i += 64) s_list[i] = full ? i : s_slot2ind[i];
+            }
+            __syncthreads();
+            // ---- _cdPass! (coordinate_descent.jl:94-110), 64 positions of the visit list at a time: lane l owns position
+            // c0 + l for the whole chunk and keeps its coordinate's a, omega, beta, slot links AND gradient in registers.
+            // A step evaluates every lane's visit against its current g, takes the first lane (from `done` on) that
+            // moves -- the lanes before it are settled exactly, g does not change until something moves -- and applies
+            // the move: each lane corrects its own g with ONE read of the mover's Gram column (g_k -= h G_k,km), while
+            // the update of the whole vector in LDS (for the chunks and passes to come) runs beside it.  The critical
+            // path of a step is that one read plus the scalar update. ----
+            double maxH = 0.0;
+            for (int c0 = 0; c0 < L; c0 += 64) {
+                const int idx = c0 + lane;
+                const bool valid = idx < L;
+                const int k = valid ? s_list[idx] : 0;
+                const double a = s_a[k], om = s_om[k];
+                double oldv = s_beta[k], gk = s_g[k];
+                int islot = s_ind2slot[k], cslot_own = s_colslot[k];
+                // least squares: the threshold lambda0 omega_k (n / a_k) of visit_update (kernels.hpp), same expression, once per chunk
+                const double thr_ls = lambda0 * om * (n_total / a);
+                int done = 0;
+                for (;;) {
+                    VisitOut o{0.0, 0, 0};
+                    if constexpr (SQRT) {
+                        o = visit_update(1, lambda0, n_total, a, gk, q, oldv, om);
+                    } else {
+                        const double v = oldv + gk / a;
+                        o.tch = (v != 0.0) ? 1 : 0;
+                        o.nv = soft_threshold(v, thr_ls);
+                    }
+                    const double hh = o.nv - oldv;
+                    const bool moves = valid && lane >= done && !(hh == 0.0);  // a NaN step "moves" (it propagates, as in the reference)
+                    const unsigned long long mmask = __ballot(moves);
+                    const int first = __builtin_amdgcn_readfirstlane(mmask ? (int)__builtin_ctzll(mmask) : 64);   // wave-uniform, in an SGPR
+                    const bool has_mover = first < 64;
+                    // the mover's Gram column: requested before anything else of the step (from LDS if it has moved before)
+                    int km = 0, cslot = -1;
+                    double cv[NP], gcol_own = 0.0;
+                    if (has_mover) {
+                        km = __builtin_amdgcn_readlane(k, first);
+                        cslot = __builtin_amdgcn_readlane(cslot_own, first);
+                        if (cslot < 0) {
+                            const double* __restrict__ col = G + (int64_t)km * p;
+                            gcol_own = col[k];
+#pragma unroll
+                            for (int t = 0; t < NP; ++t) cv[t] = col[min(lane + 64 * t, p - 1)];
+                        } else {
+                            gcol_own = s_cols[(size_t)cslot * p + k];
+                        }
+                    }
+                    if (__ballot(valid && o.dom != 0 && lane >= done && lane <= first)) dom_any = 1;
+                    // SparseIterate bookkeeping of the settled visits [done, first), in order: a pre-prox non-zero appends a
+                    // slot (x[k] += b/a), cdprox! then stores the unchanged value.  Ranked by ballot: no two lanes share a coordinate
+                    {
+                        const bool app = valid && lane >= done && lane < first && o.tch != 0 && islot == 0;
+                        const unsigned long long amask = __ballot(app);
+                        if (app) { islot = nnz + __popcll(amask & below) + 1; s_slot2ind[islot - 1] = k; s_ind2slot[k] = islot; }
+                        nnz += __popcll(amask);
+                    }
+                    steps += 1;
+                    if (!has_mover) break;
+                    // ---- the visit that moves: everything about it is broadcast from its lane ----
+                    const double nv = readlane_f64(o.nv, first), h = readlane_f64(hh, first), bm = readlane_f64(gk, first),
+                                 am = readlane_f64(a, first);
+                    const int tch = __builtin_amdgcn_readlane(o.tch, first);
+                    const bool appm = __builtin_amdgcn_readlane(islot, first) == 0 && (tch != 0 || nv != 0.0);
+                    if (lane == first) {
+                        if (appm) { islot = nnz + 1; s_slot2ind[nnz] = km; s_ind2slot[km] = nnz + 1; }
+                        oldv = nv;
+                        s_beta[km] = nv;
+                    }
+                    if (appm) nnz += 1;
+                    const double ah = fabs(h);
+                    if (ah > maxH) maxH = ah;                               // a NaN h never raises maxH (coordinate_descent.jl:104)
+                    gk = fma(-h, gcol_own, gk);                             // this lane's own gradient: no trip through s_g
+                    if (cslot >= 0) {
+                        // all reads first (one LDS round trip), then the arithmetic and the stores
+                        const double* colc = s_cols + (size_t)cslot * p;
+                        double gv[NP];
+#pragma unroll
+                        for (int t = 0; t < NP; ++t) { const int j = min(lane + 64 * t, p - 1); cv[t] = colc[j]; gv[t] = s_g[j]; }
+#pragma unroll
+                        for (int t = 0; t < NP; ++t)
+                            if (lane + 64 * t < p) s_g[lane + 64 * t] = fma(-h, cv[t], gv[t]);
+                    } else {
+                        const bool keep = ncached < ncache;
+                        double* colc = s_cols + (size_t)(keep ? ncached : 0) * p;
+                        double gv[NP];
+#pragma unroll
+                        for (int t = 0; t < NP; ++t) gv[t] = s_g[min(lane + 64 * t, p - 1)];
+#pragma unroll
+                        for (int t = 0; t < NP; ++t) {
+                            const int j = lane + 64 * t;
+                            if (j < p) { s_g[j] = fma(-h, cv[t], gv[t]); if (keep) colc[j] = cv[t]; }
+                        }
+                        if (keep) {
+                            if (lane == first) { cslot_own = ncached; s_colslot[km] = ncached; }
+                            ncached += 1;
+                            __syncthreads();                                // the column is in LDS before a later step gathers from it
+                        }
+                    }
+                    if constexpr (SQRT) { q = q - 2.0 * h * bm + h * h * am; if (q < 0.0) q = 0.0; }
+                    done = first + 1;
+                    if (done >= 64) break;
+                }
+                __syncthreads();                                            // s_g, s_beta and the slot links as the next chunk / pass reads them
+            }
+            // ---- dropzeros!(x): swap-with-last (sparse_iterate.hpp), as a match of holes and fillers.  With m slots holding
+            // non-zeros, the zero slots below m are the holes; scanning forward, each is filled by the LAST slot not yet
+            // taken that holds a non-zero -- the r-th hole (ascending) by the r-th non-zero slot from the end (descending),
+            // all of which lie at or beyond m ----
+            {
+                int m = 0;
+                for (int s0 = 0; s0 < nnz; s0 += 64) {
+                    const int s = s0 + lane;
+                    m += __popcll(__ballot(s < nnz && s_beta[s_slot2ind[s < nnz ? s : 0]] != 0.0));
+                }
+                if (m < nnz) {                                              // (nothing to drop: the usual end of an active pass)
+                // holes, ascending -> s_order[r];  fillers, descending -> s_draw[r]
+                int nh = 0, nf = 0;
+                for (int s0 = 0; s0 < m; s0 += 64) {
+                    const int s = s0 + lane;
+                    const bool hole = s < m && s_beta[s_slot2ind[s < m ? s : 0]] == 0.0;
+                    const unsigned long long hm = __ballot(hole);
+                    if (hole) s_order[nh + __popcll(hm & below)] = s;
+                    nh += __popcll(hm);
+                }
+                for (int s1 = nnz; s1 > m; s1 -= 64) {                     // chunks from the end; inside a chunk lane 0 is the last slot
+                    const int s = s1 - 1 - lane;
+                    const bool fil = s >= m && s_beta[s_slot2ind[s >= m ? s : m]] != 0.0;
+                    const unsigned long long fm = __ballot(fil);
+                    if (fil) s_draw[nf + __popcll(fm & below)] = s;
+                    nf += __popcll(fm);
+                }
+                __syncthreads();
+                // every slot that holds a zero loses its coordinate -> slot link; then the fillers move into the holes
+                for (int s = lane; s < nnz; s += 64) { const int ks = s_slot2ind[s]; if (s_beta[ks] == 0.0) s_ind2slot[ks] = 0; }
+                __syncthreads();
+                for (int r = lane; r < nh; r += 64) { const int kf = s_slot2ind[s_draw[r]]; s_slot2ind[s_order[r]] = kf; s_ind2slot[kf] = s_order[r] + 1; }
+                nnz = m;
+                }
+            }
+            __syncthreads();
+            passes += 1; visits += L; lastH = maxH;
+            if (full) full_passes += 1;
+            prev_conv = conv;
+            conv = maxH < optTol;
+            if (prev_conv && conv) { converged = 1; break; }
+        }
+    }
+    for (int k = lane; k < p; k += 64) { beta[k] = s_beta[k]; beta_out[k] = s_beta[k]; }
+    for (int s = lane; s < nnz; s += 64) sup[s] = s_slot2ind[s];
+    if (lane == 0) {
+        ctl->rng = rng; ctl->passes = passes; ctl->full_passes = full_passes; ctl->visits = visits;
+        ctl->converged = converged; ctl->domain_error = dom_any; ctl->maxH = lastH; ctl->nnz = nnz;
+        ctl->steps = steps; ctl->cycles = __builtin_amdgcn_s_memtime() - t0c; ctl->ticks = __builtin_amdgcn_s_memrealtime() - t0r;
+    }
+}
+
+// G[k][b0 + b] <- the cross products of one k_cross batch (records of 64 x 32, tile-major): the batch's columns of the
+// full Gram matrix, without a trip through the host
+__global__ __launch_bounds__(256) void k_small_unpack(const double* __restrict__ cross, int64_t p, int b0, int nbc,
+                                                      double* __restrict__ Gfull) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p) return;
+    const int64_t L = k / kCrossA, i = k % kCrossA;
+    for (int b = 0; b < nbc; ++b)
+        Gfull[(int64_t)(b0 + b) * p + k] = cross[L * kCrossRec + ((i >> 4) * kCrossTB + (b >> 4)) * 256 + (i & 15) * 16 + (b & 15)];
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+inline size_t small_sup_off() { return (sizeof(SmallCtl) + 15) / 16 * 16; }
+inline size_t small_beta_off(int64_t p) { return small_sup_off() + ((size_t)p * sizeof(int32_t) + 15) / 16 * 16; }
+inline size_t small_io_bytes(int64_t p) { return small_beta_off(p) + (size_t)p * sizeof(double); }
+
+inline bool small_applicable(const cdh_handle_s* h, const cdh_options* o) {
+    return h->small.enabled && !sharded(h) && h->p <= kSmallMaxP && (size_t)h->ld * (size_t)h->p * h->esz <= kSmallMaxBytes &&
+           h->gc.mode != 3 /* tests force the gradient cache's own path with mode 3 */ && (h->loss != CDH_WLS || h->has_w) &&
+           o->numSteps + 1 <= kSmallMaxLam && o->numSteps >= 1;
+}
+
+int32_t small_prepare(cdh_handle h) {     // buffers + the full Gram matrix of the resident X
+    SmallPath& sp = h->small;
+    GradCache& c = h->gc;
+    if (!sp.d_G) {
+        CHK(gc_size(h));                  // k_cross's scratch (d_cross, d_cross_part, d_cols) is the gradient cache's
+        if (!c.d_cross) { sp.enabled = false; return CDH_OK; }
+        bool fits = hipMalloc((void**)&sp.d_G, sizeof(double) * (size_t)h->p * (size_t)h->p) == hipSuccess &&
+                    // one block for everything that crosses the bus per solve: [SmallCtl][support: p int32][beta: p doubles]
+                    hipMalloc((void**)&sp.d_ca, sizeof(double) * (2 * (size_t)h->p + 1)) == hipSuccess &&
+                    hipMalloc((void**)&sp.d_io, small_io_bytes(h->p)) == hipSuccess &&
+                    hipHostMalloc((void**)&sp.h_io, small_io_bytes(h->p)) == hipSuccess;
+        if (!fits) { (void)hipGetLastError(); sp.enabled = false; return CDH_OK; }
+        sp.d_ctl = reinterpret_cast<SmallCtl*>(sp.d_io); sp.h_ctl = reinterpret_cast<SmallCtl*>(sp.h_io);
+        sp.d_sup = reinterpret_cast<int32_t*>(sp.d_io + small_sup_off()); sp.h_sup = reinterpret_cast<int32_t*>(sp.h_io + small_sup_off());
+        sp.d_beta = reinterpret_cast<double*>(sp.d_io + small_beta_off(h->p)); sp.h_beta = reinterpret_cast<double*>(sp.h_io + small_beta_off(h->p));
+        // dynamic LDS of the solve kernel: the p-sized state, then as many Gram columns as the rest of the CU's LDS holds
+        // (the whole 160 KB when the runtime grants it, else what fits the default 64 KB)
+        const size_t state = (size_t)h->p * (4 * sizeof(double) + 6 * sizeof(int32_t));
+        size_t budget = (size_t)160 * 1024;
+        auto widen = [&](auto kernel) {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget) == hipSuccess;
+        };
+        if (!(widen(&k_solve_small<false, 4>) && widen(&k_solve_small<true, 4>) && widen(&k_solve_small<false, 8>) &&
+              widen(&k_solve_small<true, 8>) && widen(&k_solve_small<false, 16>) && widen(&k_solve_small<true, 16>))) {
+            (void)hipGetLastError();
+            budget = (size_t)64 * 1024;
+        }
+        sp.ncache = (int)std::min<size_t>(256, (budget - state) / ((size_t)h->p * sizeof(double)));
+        sp.lds_bytes = (unsigned)(state + (size_t)sp.ncache * (size_t)h->p * sizeof(double));
+    }
+    if (!sp.c_valid) {                // c = X'y (X'Wy), a = diag(G), y'y: one dots pass over X with y in r's place, once per y
+        CHK(col_dots(h, 0, h->p, h->y, h->has_w));
+        HIPCHK(h, hipMemcpyAsync(sp.d_ca, h->d_colout, sizeof(double) * 2 * (size_t)h->p, hipMemcpyDeviceToDevice, h->stream));
+        sp.h_c.resize((size_t)(2 * h->p));
+        HIPCHK(h, hipMemcpyAsync(sp.h_c.data(), h->d_colout, sizeof(double) * 2 * (size_t)h->p, hipMemcpyDeviceToHost, h->stream));
+        CHK(resid_moments_dev(h, h->y));
+        HIPCHK(h, hipMemcpyAsync(sp.d_ca + 2 * h->p, h->d_red + 1, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        sp.yy = h->h_red[1];
+        sp.c_valid = true;
+    }
+    if (sp.G_valid) return CDH_OK;
+    const int64_t launches = (h->p + kCrossA - 1) / kCrossA;
+    std::vector<int64_t> cols((size_t)kCrossB);
+    for (int64_t b0 = 0; b0 < h->p; b0 += kCrossB) {
+        const int nbc = (int)std::min<int64_t>(kCrossB, h->p - b0);
+        for (int b = 0; b < nbc; ++b) cols[(size_t)b] = b0 + b;
+        HIPCHK(h, hipMemcpyAsync(c.d_cols, cols.data(), sizeof(int64_t) * (size_t)nbc, hipMemcpyHostToDevice, h->stream));
+        CHK(dispatch(h, [&](auto* t) {
+            using T = std::remove_pointer_t<decltype(t)>;
+            const dim3 grid((unsigned)c.cross_GX, (unsigned)c.cross_J), block(64 * kGramWaves);
+            if (h->has_w)
+                hipLaunchKernelGGL((k_cross<T, true>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc,
+                                   (const T*)h->w, c.d_cross_part);
+            else
+                hipLaunchKernelGGL((k_cross<T, false>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc,
+                                   (const T*)nullptr, c.d_cross_part);
+            return CDH_OK;
+        }));
+        hipLaunchKernelGGL(k_cross_reduce, dim3(kCrossRec / 256, (unsigned)launches), dim3(256), 0, h->stream, c.d_cross_part,
+                           c.cross_J, c.d_cross);
+        hipLaunchKernelGGL(k_small_unpack, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_cross, h->p, (int)b0, nbc,
+                           sp.d_G);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(h->stream));     // `cols` is reused by the next batch
+    }
+    sp.G_valid = true;
+    sp.n_gram += 1;
+    return CDH_OK;
+}
+
+// the solves lambdas[0 .. nlam) of one coordinateDescent! call, back to back in one launch; r must describe the handle's
+// iterate on entry (initialize! has run, or the carried residual is being reused)
+// from_c: the residual of the handle's iterate is y - X beta by definition (initialize! semantics), so nothing is read
+// from r: g = X'y - G beta inside the kernel, and r is left to be rebuilt lazily (r_lazy).  Otherwise (cdh_solve: "assumes
+// r is initialised", whatever it holds) g = X'r is taken from the device's r and the moves become pending updates of it.
+int32_t small_solve(cdh_handle h, const cdh_options* o, const double* lambdas, int nlam, uint64_t* rng, cdh_stats* st, bool from_c) {
+    SmallPath& sp = h->small;
+    const double *ga = sp.d_ca, *qin = sp.d_ca + 2 * h->p;
+    if (!from_c) {
+        CHK(col_dots(h, 0, h->p, h->r, h->has_w));                  // g = X'r (X'Wr), a = diag(G): d_colout
+        if (h->loss == CDH_SQRT) CHK(resid_moments_dev(h));         // r'r: d_red[1]
+        ga = h->d_colout; qin = h->d_red + 1;
+    }
+    SmallCtl& ctl = *sp.h_ctl;
+    ctl.g_from_c = from_c ? 1 : 0;
+    for (int i = 0; i < nlam; ++i) ctl.lambdas[i] = lambdas[i];
+    ctl.nlam = nlam; ctl.randomize = o->randomize ? 1 : 0; ctl.loss = h->loss; ctl.has_omega = h->has_omega ? 1 : 0;
+    ctl.maxIter = o->maxIter; ctl.optTol = o->optTol; ctl.n_total = (double)h->n_total; ctl.rng = *rng;
+    ctl.nnz_in = (int32_t)h->x.nnz();
+    for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) sp.h_sup[s_] = (int32_t)h->x.coord(s_);
+    // down: the control block and the support, one copy; back: those two and beta, one copy
+    HIPCHK(h, hipMemcpyAsync(sp.d_io, sp.h_io, small_sup_off() + sizeof(int32_t) * (size_t)h->x.nnz(), hipMemcpyHostToDevice, h->stream));
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(64), sp.lds_bytes, h->stream, sp.d_ctl, (int)h->p, sp.ncache, ga, sp.d_G,
+                           h->omega, qin, h->beta, sp.d_sup, sp.d_beta);
+    };
+    const bool sq = h->loss == CDH_SQRT;
+    if (h->p <= 256) { if (sq) go(k_solve_small<true, 4>); else go(k_solve_small<false, 4>); }
+    else if (h->p <= 512) { if (sq) go(k_solve_small<true, 8>); else go(k_solve_small<false, 8>); }
+    else { if (sq) go(k_solve_small<true, 16>); else go(k_solve_small<false, 16>); }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(sp.h_io, sp.d_io, small_io_bytes(h->p), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // what moved becomes pending residual updates (r_actual = r_virtual + X * pending: sync_r applies them before anything
+    // reads r) and, for a gradient cache that holds a reference, pending moves like those of any other visit
+    GradCache& c = h->gc;
+    if (from_c) {                      // r was never read and is not touched: it stands for the new iterate, to be formed on demand
+        if (c.valid || c.beta_ok) gc_invalidate(h, false);
+        drop_r_pending(h);
+    }
+    for (int64_t k = 0; k < h->p && !from_c; ++k) {
+        const double d = sp.h_beta[k] - h->x.get(k);
+        if (d == 0.0) continue;
+        if (!h->r_in_pending[(size_t)k]) { h->r_in_pending[(size_t)k] = 1; h->r_pending_list.push_back(k); }
+        h->r_pending[(size_t)k] += d;
+        if (d != d) { if (c.valid || c.beta_ok) gc_invalidate(h, false); continue; }
+        if (c.beta_ok) c.beta_ref[(size_t)k] += d;
+        if (c.valid) {
+            c.dbeta[(size_t)k] += d;
+            if (!c.in_moved[(size_t)k]) { c.in_moved[(size_t)k] = 1; c.moved.push_back(k); }
+        }
+    }
+    c.q_valid = false;
+    h->x.clear();
+    for (int32_t s_ = 0; s_ < ctl.nnz; ++s_) h->x.set(sp.h_sup[s_], sp.h_beta[sp.h_sup[s_]]);
+    if (from_c) { h->r_lazy = true; h->x_lazy = h->x; h->r_consistent = true; }
+    *rng = ctl.rng;
+    st->passes += ctl.passes; st->full_passes += ctl.full_passes; st->visits += ctl.visits;
+    st->converged = ctl.converged; st->maxH = ctl.maxH;
+    if (ctl.domain_error) h->domain_error = true;
+    st->domain_error = h->domain_error ? 1 : 0;
+    sp.n_solves += nlam;
+    return CDH_OK;
+}

@@ -226,6 +226,19 @@ int32_t cdh_cache_stats(cdh_handle h, int64_t *out10);
  * -- the quantity the certificates' relative margin (1e-9 for fp64 storage) has to cover.
  * out3 = {drift at the last re-reference, the largest seen on this handle, re-references measured}. */
 int32_t cdh_cache_drift(cdh_handle h, int32_t rereference_now, double *out3);
+/* Problems that fit on chip -- p <= 1024 and n p sizeof(T) <= 16 MB, one process: the reference's own test and
+ * benchmark shapes (test/lasso.jl:76-101, benchmark/cd_bench.jl:8-14) -- are solved in ONE launch: the handle keeps the
+ * full Gram matrix X'X (X'WX) of the resident X, and one wave runs the whole of _coordinateDescent!
+ * (coordinate_descent.jl:65-92; a cold start's numSteps + 1 solves, :32-36, in the same launch) in covariance form, with
+ * the SparseIterate bookkeeping that fixes the visit order of active passes replayed on the device.  Same iterates as the
+ * streamed sweeps up to rounding.  On by default (environment CDH_SMALL_PATH=0, or on = 0 here, keeps every solve on the
+ * streamed kernels).  cdh_onchip_stats: out2 = {solves run this way, Gram matrices built}. */
+int32_t cdh_set_onchip_solve(cdh_handle h, int32_t on);
+int32_t cdh_onchip_stats(cdh_handle h, int64_t *out2);
+/* Of the last one-launch solve: out3 = {visit steps taken (a step settles a run of positions and makes at most one
+ * move), shader cycles the kernel ran for, the same span in 100 MHz ticks} -- cycles / ticks * 0.1 is the clock in GHz
+ * the chip held for a one-wave kernel. */
+int32_t cdh_onchip_last(cdh_handle h, int64_t *out3);
 /* Replay each pass from a captured hipGraph instead of individual launches (the north_star's
  * "full sweep captured under hipGraph").  Works on row shards too: the direct exchange takes its epoch
  * from device memory, RCCL all-reduces are captured with the kernels around them; only the host-staged

@@ -112,6 +112,21 @@ def test_cfg5_one_rank_shard_full_size_properties():
         cd.coordinateDescent_(x, f, cd.ProxL1(lam * sigma_hat, om), cdo)
         _, ss3 = _moments(f)
         assert abs(np.sqrt(ss3 / n) - sigma_hat) / sigma_hat < 1e-2
+        # round 3: the gradient cache serves fp32 storage.  The same sigma loop from x = 0 with the cache off and with
+        # it engaged from the first full pass: same sigma (1e-6 relative), same beta (2e-5: the cache's g follows the
+        # fp64 problem, the streamed sweep the rounding of its fp32 residual), the same number of passes in the last solve.
+        res = {}
+        for mode in (0, 2):
+            f.set_gradient_cache(mode)
+            before = f.cache_stats()
+            xm = cd.SparseIterate(p)
+            sm = cd.scaledLasso_(xm, f, None, lam, om, cd.IterLassoOptions(optionsCD=cdo))
+            after = f.cache_stats()
+            res[mode] = (sm.sigma, xm.dense(), f.last_stats["passes"], {k: after[k] - before[k] for k in after})
+        assert abs(res[2][0] - res[0][0]) / res[0][0] < 1e-6 and res[2][2] == res[0][2], (res[0][0], res[2][0], res[0][2], res[2][2])
+        np.testing.assert_allclose(res[2][1], res[0][1], rtol=0, atol=2e-5)
+        assert res[0][3]["passes"] == 0 and res[2][3]["passes"] >= 2 and res[2][3]["device_passes"] >= 2, res[2][3]
+        assert res[2][3]["covariance_visits"] > 100 and res[2][3]["gram_columns"] >= int(act.sum()), res[2][3]
     finally:
         f.close()
 
@@ -186,6 +201,13 @@ def test_cfg3_full_size_path_properties():
             if i in (30, 60, 99):
                 keep[i] = beta.copy()
         cd._lib.check(f._L.cdh_set_reuse_residual(f._h, 0), f._h)
+        # the gradient cache served this path (engaged by its default rent-or-buy policy), mostly in whole passes on
+        # the device, without a rollback; its carried gradient, taken afresh from X right now, had drifted by far less
+        # than the certificates' 1e-9 relative margin ("bound and report the cached gradient's drift")
+        cs = f.cache_stats()
+        assert cs["passes"] > 100 and cs["device_passes"] > 100 and cs["rollbacks"] == 0 and cs["covariance_visits"] > 10_000, cs
+        drift = f.cache_drift(rereference_now=True)
+        assert drift["measured"] >= 1 and drift["max"] < 1e-10, drift
         # optTol bounds |h| by 1e-7, i.e. the gradient of a visited coordinate by 1e-7 * ||X_k||^2 / n
         assert worst_on < 1e-5 and worst_off < 1 + 1e-5, (worst_on, worst_off)
         # (a few of the 100 planted coefficients are smaller than the last threshold: 95 survive on this seed)

@@ -919,6 +919,100 @@ def test_gradient_cache_path_matches_oracle_and_plain_passes(loss, rand):
         assert s["gram_columns"] >= xo.nnz and s["reference_passes"] <= 3, s
 
 
+@pytest.mark.parametrize("rand", [False, True], ids=["ordered", "random"])
+def test_gradient_cache_serves_weighted_ls_loss(rand):
+    """CDWeightedLSLoss (cd_differentiable_function.jl:165-194) through the gradient cache (round 3): g = X'Wr,
+    Gram columns X'WX_j (k_cross with the weight on the B operand), covariance-form visits, whole passes on the
+    device.  Same beta as the oracle at every lambda (1e-10), same support ORDER and pass counts as the cache-off run."""
+    rng, X, Y = _problem(61, 4000, 520, 12, noise=1.0)
+    X *= rng.uniform(0.5, 2.0, size=520)
+    w = rng.random(4000) + 0.5
+    lams = np.exp(np.linspace(np.log(0.35), np.log(0.04), 12))
+    o = dict(maxIter=3000, optTol=1e-10, randomize=rand, seed=17)
+    xo, fo, want = O.SparseIterate(520), O.CDWeightedLSLoss(Y, X, w), []
+    for lam in lams:
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        want.append((xo.dense().copy(), xo.nzval2ind.tolist(), st["passes"]))
+    assert 8 < xo.nnz < 130
+    stats = {}
+    for mode in (3, 0):
+        f = cd.CDWeightedLSLoss(Y, X, w)
+        f.set_gradient_cache(mode)                      # default sweep: block, B = 32
+        x = cd.SparseIterate(520)
+        for lam, (beta, sup, passes) in zip(lams, want):
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+            np.testing.assert_allclose(x.dense(), beta, rtol=0, atol=BETA_TOL)
+            assert x.nzval2ind.tolist() == sup and f.last_stats["passes"] == passes, (mode, lam)
+        np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-9)
+        stats[mode] = f.cache_stats()
+        f.close()
+    s3 = stats[3]
+    assert stats[0]["passes"] == 0 and s3["passes"] >= 10 and s3["covariance_visits"] > 0 and s3["device_passes"] > 0, s3
+    assert s3["gram_columns"] >= xo.nnz and s3["settled_visits"] > 5 * s3["exact_visits"] > 0, s3
+
+
+def test_gradient_cache_serves_fp32_storage():
+    """fp32 storage of X, y, r through the gradient cache (round 3).  The certificates allow for the rounding of the
+    fp32 residual (Ctrl.cert_abs: 64 * 2^-24 * sqrt((U + 1) y'y / n) * sqrt(a_k), grad_cache.hpp); the cache's g is
+    carried in fp64 from Gram entries summed in fp64, so it follows the fp64 problem rather than the rounding of the
+    streamed fp32 sweep.  Declared tolerances: beta within 3e-4 of the fp64 oracle (the tolerance of every fp32 test
+    here), within 2e-5 of the cache-off fp32 run, the same number of passes at every lambda."""
+    rng, X, Y = _problem(62, 6000, 500, 12, noise=1.0)
+    X *= rng.uniform(0.5, 2.0, size=500)
+    lams = np.exp(np.linspace(np.log(0.3), np.log(0.04), 10))
+    o = dict(maxIter=3000, optTol=1e-6, randomize=False)
+    lo, bo = O.LassoPath(X, Y, lams, O.CDOptions(**dict(o, optTol=1e-10)), standardizeX=False)
+    X32, Y32 = X.astype(np.float32), Y.astype(np.float32)
+    out = {}
+    for mode in (3, 0):
+        f = cd.CDLeastSquaresLoss(Y32, X32)
+        f.set_gradient_cache(mode)
+        x = cd.SparseIterate(500)
+        betas, passes = [], []
+        for lam in lams:
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+            betas.append(x.dense().copy())
+            passes.append(f.last_stats["passes"])
+        out[mode] = (betas, passes, f.cache_stats(), f.r)
+        f.close()
+    for i in range(len(lams)):
+        np.testing.assert_allclose(out[3][0][i], bo[i], rtol=0, atol=3e-4)
+        np.testing.assert_allclose(out[3][0][i], out[0][0][i], rtol=0, atol=2e-5)
+    assert out[3][1] == out[0][1], (out[3][1], out[0][1])
+    s3 = out[3][2]
+    assert s3["passes"] >= 8 and s3["covariance_visits"] > 0 and s3["device_passes"] > 0 and s3["gram_columns"] >= np.count_nonzero(bo[-1]), s3
+    assert out[3][3].dtype == np.float32
+    np.testing.assert_allclose(out[3][3], Y - X @ out[3][0][-1], rtol=0, atol=2e-3)    # the caught-up residual
+
+
+def test_gradient_cache_keeps_g_on_the_device_and_reports_its_drift():
+    """Whole full passes run on the device (scan -> covariance-form blocks with the certificate re-check in the g
+    update): the stats say so, the iterates are the oracle's, and cdh_cache_drift -- which takes the carried gradient
+    afresh from X and measures max_k |g_carried - X_k'r| / thr_k -- stays orders of magnitude inside the certificates'
+    1e-9 margin after a few thousand covariance-form updates."""
+    rng, X, Y = _problem(63, 5000, 700, 15, noise=1.0)
+    lams = np.exp(np.linspace(np.log(0.3), np.log(0.03), 25))
+    o = dict(maxIter=3000, optTol=1e-10, randomize=False)
+    f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+    f.set_gradient_cache(3)
+    x, xo = cd.SparseIterate(700), O.SparseIterate(700)
+    for lam in lams:
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"]
+    cs = f.cache_stats()
+    assert cs["device_passes"] >= 20 and cs["device_passes"] >= cs["passes"] - 3 and cs["covariance_visits"] > 1000, cs
+    assert f.cache_drift()["measured"] == 0
+    d = f.cache_drift(rereference_now=True)
+    assert d["measured"] == 1 and 0.0 <= d["last"] == d["max"] < 1e-11, d
+    assert f.cache_stats()["reference_passes"] == cs["reference_passes"] + 1
+    cd.coordinateDescent_(x, f, cd.ProxL1(0.025), cd.CDOptions(**o))                 # and the cache goes on from the fresh g
+    O.coordinateDescent_(xo, fo, O.ProxL1(0.025), O.CDOptions(**o))
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+    f.close()
+
+
 def test_gradient_cache_follows_new_iterates_new_y_and_cold_starts():
     """What invalidates or shifts the cached gradient: a warm start from a DIFFERENT x (the difference is
     folded in as moves), a cold start (x zeroed, 51 continuation solves -- all served from the cache), a
