@@ -110,9 +110,13 @@ struct GradCache {
     std::vector<int64_t> pass_idx_host;   // ... and what it holds
     int32_t *d_pos_of = nullptr, *d_upos = nullptr;
     uint8_t* d_setflag = nullptr;
-    cdk::CovScanOut* d_scan = nullptr;
-    cdk::CovScanOut* h_scan = nullptr;    // pinned
-    int32_t* h_upos = nullptr;            // pinned, cap entries
+    // the scan's counters sit at the head of the buffer of unsettled positions (one copy brings both back); the results of
+    // a pass come back through k_cov_pack's block
+    int32_t *d_scanbuf = nullptr, *h_scanbuf = nullptr;   // [CovScanOut: 4 int32][positions: cap]; h_: pinned
+    cdk::CovScanOut* d_scan = nullptr;    // = d_scanbuf
+    cdk::CovScanOut* h_scan = nullptr;    // = h_scanbuf
+    int32_t* h_upos = nullptr;            // = h_scanbuf + 4
+    double *d_pack = nullptr, *h_pack = nullptr;          // kPackHead + 2.5 cap doubles; h_: pinned
     bool a_dev_ok = false;                // d_a mirrors c.a
     double yy = 0.0;                      // y'y over all shards (fp32 certificate margin), valid while yy_ok
     bool yy_ok = false;
@@ -1002,10 +1006,10 @@ void free_all(cdh_handle h) {
     if (h->small.h_io) (void)hipHostFree(h->small.h_io);
     {
         GradCache& c = h->gc;
-        void* dv[] = {c.d_a, c.d_g_snap, c.d_beta_snap, c.d_qs, c.d_pass_idx, c.d_pos_of, c.d_upos, c.d_setflag, c.d_scan};
+        void* dv[] = {c.d_a, c.d_g_snap, c.d_beta_snap, c.d_qs, c.d_pass_idx, c.d_pos_of, c.d_scanbuf, c.d_setflag, c.d_pack};
         for (void* q : dv) if (q) (void)hipFree(q);
-        if (c.h_scan) (void)hipHostFree(c.h_scan);
-        if (c.h_upos) (void)hipHostFree(c.h_upos);
+        if (c.h_scanbuf) (void)hipHostFree(c.h_scanbuf);
+        if (c.h_pack) (void)hipHostFree(c.h_pack);
     }
     if (h->h_xchg) (void)hipHostFree(h->h_xchg);
     if (h->p2p_timeout) (void)hipHostFree(h->p2p_timeout);

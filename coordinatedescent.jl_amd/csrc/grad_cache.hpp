@@ -87,14 +87,16 @@ int32_t gc_dev_upload(cdh_handle h) {
                hipMalloc((void**)&c.d_qs, sizeof(double) * (size_t)h->cap) == hipSuccess &&
                hipMalloc((void**)&c.d_pass_idx, sizeof(int64_t) * (size_t)h->cap) == hipSuccess &&
                hipMalloc((void**)&c.d_pos_of, sizeof(int32_t) * (size_t)p) == hipSuccess &&
-               hipMalloc((void**)&c.d_upos, sizeof(int32_t) * (size_t)h->cap) == hipSuccess &&
+               hipMalloc((void**)&c.d_scanbuf, sizeof(int32_t) * (size_t)(h->cap + 4)) == hipSuccess &&
                hipMalloc((void**)&c.d_setflag, (size_t)p) == hipSuccess &&
-               hipMalloc((void**)&c.d_scan, sizeof(cdk::CovScanOut)) == hipSuccess &&
-               hipHostMalloc((void**)&c.h_scan, sizeof(cdk::CovScanOut)) == hipSuccess &&
-               hipHostMalloc((void**)&c.h_upos, sizeof(int32_t) * (size_t)h->cap) == hipSuccess;
+               hipMalloc((void**)&c.d_pack, sizeof(double) * (size_t)(kPackHead + 3 * h->cap)) == hipSuccess &&
+               hipHostMalloc((void**)&c.h_scanbuf, sizeof(int32_t) * (size_t)(h->cap + 4)) == hipSuccess &&
+               hipHostMalloc((void**)&c.h_pack, sizeof(double) * (size_t)(kPackHead + 3 * h->cap)) == hipSuccess;
         if (!fits) (void)hipGetLastError();
         CHK(all_ranks_agree(h, fits, &fits));
         if (!fits) { c.cov = false; return CDH_OK; }
+        c.d_scan = reinterpret_cast<cdk::CovScanOut*>(c.d_scanbuf); c.d_upos = c.d_scanbuf + 4;
+        c.h_scan = reinterpret_cast<cdk::CovScanOut*>(c.h_scanbuf); c.h_upos = c.h_scanbuf + 4;
         HIPCHK(h, hipMemsetAsync(c.d_qs, 0, sizeof(double) * (size_t)h->cap, h->stream));
         c.g_dev_ok = false; c.a_dev_ok = false;
     }
@@ -245,6 +247,24 @@ int32_t launch_cov_blocks(cdh_handle h, int m, bool chk = false, int m_pass = 0)
     return launch_cov_chunk<1>(h, m, chk, m_pass);
 }
 
+// the results of m covariance-form visits (and the control block, and with `scan` the re-check's verdict) back to the
+// host's staging arrays: one gather kernel, one copy, one synchronisation
+int32_t cov_fetch_results(cdh_handle h, int m, bool scan) {
+    GradCache& c = h->gc;
+    hipLaunchKernelGGL(k_cov_pack, dim3((unsigned)((std::max(m, 1) + 255) / 256)), dim3(256), 0, h->stream, h->d_ctrl,
+                       scan ? c.d_scan : (const cdk::CovScanOut*)nullptr, h->d_hs, h->d_newval, h->d_touched, m, c.d_pack);
+    HIPCHK(h, hipGetLastError());
+    const size_t bytes = sizeof(double) * (size_t)(kPackHead + 2 * m) + sizeof(int32_t) * (size_t)m;
+    HIPCHK(h, hipMemcpyAsync(c.h_pack, c.d_pack, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(h->h_ctrl, c.h_pack, sizeof(Ctrl));
+    if (scan) std::memcpy(c.h_scan, c.h_pack + 8, sizeof(cdk::CovScanOut));
+    std::memcpy(h->h_hs, c.h_pack + kPackHead, sizeof(double) * (size_t)m);
+    std::memcpy(h->h_newval, c.h_pack + kPackHead + m, sizeof(double) * (size_t)m);
+    std::memcpy(h->h_touched, c.h_pack + kPackHead + 2 * (size_t)m, sizeof(int32_t) * (size_t)m);
+    return CDH_OK;
+}
+
 // enqueue the visits, bring the results back into staging (h_hs / h_newval / h_touched / h_ctrl) -- nothing on the
 // host has changed yet.  g stays on the device; with `want_g` (the legacy walk re-checks skipped certificates on
 // the host) the updated g also comes back into c.g_new.
@@ -264,11 +284,7 @@ int32_t cov_run(cdh_handle h, const int64_t* idx0, int m, bool want_g) {
         c.g_new.resize((size_t)h->p);
         HIPCHK(h, hipMemcpyAsync(c.h_g_pin + h->p, c.d_g, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost, h->stream));
     }
-    HIPCHK(h, hipMemcpyAsync(h->h_hs, h->d_hs, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_newval, h->d_newval, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_touched, h->d_touched, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    CHK(cov_fetch_results(h, m, false));
     if (want_g) std::memcpy(c.g_new.data(), c.h_g_pin + h->p, sizeof(double) * (size_t)h->p);
     c.g_host_ok = false;              // d_g has moved on; c.g is the gradient BEFORE the chunk until it is accepted
     return CDH_OK;
@@ -525,8 +541,7 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
         hipLaunchKernelGGL(k_cov_scan, dim3(1), dim3(1024), 0, h->stream, c.d_g, c.d_a, h->beta, h->omega, h->d_ctrl, c.d_pass_idx, (int)m,
                            h->p, c.d_pos_of, c.d_setflag, c.d_upos, h->d_idx, c.d_g_snap, c.d_beta_snap, c.d_scan);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(c.h_scan, c.d_scan, sizeof(cdk::CovScanOut), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(c.h_upos, c.d_upos, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(c.h_scanbuf, c.d_scanbuf, sizeof(int32_t) * (size_t)(m + 4), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         cnt = c.h_scan->count;
         if (c.h_scan->nzero > 0) return CDH_OK;     // a settled coordinate with g == 0 exactly: its bookkeeping differs; the walk knows
@@ -552,12 +567,7 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
         h->chunk_dup = false;
         CHK(launch_cov_blocks(h, cnt, true, (int)m));
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(h->h_hs, h->d_hs, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->h_newval, h->d_newval, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->h_touched, h->d_touched, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(c.h_scan, c.d_scan, sizeof(cdk::CovScanOut), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        CHK(cov_fetch_results(h, cnt, true));
         if ((int64_t)c.h_scan->bad_pos < m) {       // a skipped certificate did not survive the pass's own moves: undo
             hipLaunchKernelGGL(k_cov_restore, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, h->beta, c.d_g_snap,
                                c.d_beta_snap, h->p);

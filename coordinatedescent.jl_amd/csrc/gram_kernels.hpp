@@ -925,6 +925,25 @@ __global__ __launch_bounds__(256) void k_cov_gupdate_chk(double* __restrict__ g,
     if (nmove) g[k] = acc;
 }
 
+// Everything a covariance-form pass sends back, gathered into one block: [Ctrl: 8 doubles][CovScanOut: 2][h: m][newval: m]
+// [touched: m int32] -- one copy over the bus instead of five (each costs the host several microseconds to enqueue)
+constexpr int kPackHead = 10;
+__global__ __launch_bounds__(256) void k_cov_pack(const Ctrl* ctrl, const CovScanOut* scan, const double* __restrict__ hs,
+                                                  const double* __restrict__ newval, const int32_t* __restrict__ touched, int m,
+                                                  double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        *reinterpret_cast<Ctrl*>(out) = *ctrl;
+        if (scan) *reinterpret_cast<CovScanOut*>(out + 8) = *scan;
+    }
+    if (i < m) {
+        out[kPackHead + i] = hs[i];
+        out[kPackHead + m + i] = newval[i];
+        reinterpret_cast<int32_t*>(out + kPackHead + 2 * (size_t)m)[i] = touched[i];
+    }
+}
+static_assert(sizeof(Ctrl) <= 64 && sizeof(CovScanOut) == 16, "k_cov_pack's header layout");
+
 __global__ void k_scatter_f64(double* __restrict__ dst, const int64_t* __restrict__ idx, const double* __restrict__ val, int m) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) dst[idx[i]] = val[i];

@@ -47,6 +47,7 @@ template <typename T> int run(int64_t n, int64_t p, int reps) {
     const char* gxe = getenv("CDH_CROSS_GX");
     const int GX = (int)std::max<int64_t>(1, std::min<int64_t>(nsuper, gxe ? atoi(gxe) : 4));
     const int J = (int)std::max<int64_t>(1, std::min<int64_t>(nslabs, (2 * (int64_t)cus) / GX));
+    const int J3 = (int)std::max<int64_t>(1, std::min<int64_t>(nslabs, ((int64_t)kCrossOcc * cus) / GX));   // the library's grid
     double *part, *out0, *out1;
     CK(hipMalloc(&part, sizeof(double) * (size_t)groups * J * kCrossRec));
     double* part3;
@@ -97,17 +98,19 @@ template <typename T> int run(int64_t n, int64_t p, int reps) {
     };
     bool ok = true;
     for (int nbc : {32, 16, 5}) {
-        timeit("k_cross_frag (round 2)", [&] {
+        timeit("k_cross_frag (round 2 kernel)", [&] {
             hipLaunchKernelGGL(k_cross_frag<T>, dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, part); }, out0, nbc);
         timeit("k_cross2 (LDS-DMA, plain)", [&] {
             hipLaunchKernelGGL((k_cross2<T, false, 0>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
         ok = compare("k_cross2 plain vs k_cross", out0, out1, nbc, false) && ok;
-        timeit("k_cross3 (ring of 4, plain)", [&] {
-            hipLaunchKernelGGL((k_cross<T, false, 0>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
-        ok = compare("k_cross3 plain vs k_cross", out0, out1, nbc, false) && ok;
-        timeit("k_cross3 (ring of 4, nt A)", [&] {
-            hipLaunchKernelGGL((k_cross<T, false, 2>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
-        ok = compare("k_cross3 nt vs k_cross", out0, out1, nbc, false) && ok;
+        timeit("k_cross R=4 occ2 plain", [&] {
+            hipLaunchKernelGGL((k_cross<T, false, 0, 4, 2, false>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
+        ok = compare("k_cross R=4 occ2 plain vs round 2", out0, out1, nbc, false) && ok;
+        timeit("k_cross R=4 occ2 nt", [&] {
+            hipLaunchKernelGGL((k_cross<T, false, 2, 4, 2, false>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
+        ok = compare("k_cross R=4 occ2 nt vs round 2", out0, out1, nbc, false) && ok;
+        timeit("k_cross PRODUCT (R=2 occ3 nt prio)", [&] {
+            hipLaunchKernelGGL((k_cross<T, false>), dim3(GX, J3), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part3); }, out1, nbc);
         timeit("k_cross2 (LDS-DMA, nt A)", [&] {
             hipLaunchKernelGGL((k_cross2<T, false, 2>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
         ok = compare("k_cross2 nt vs k_cross", out0, out1, nbc, false) && ok;
@@ -132,30 +135,30 @@ template <typename T> int run(int64_t n, int64_t p, int reps) {
         timeit("k_cross2 matrix only + stamps", [&] {
             hipLaunchKernelGGL((k_cross2<T, false, 2, 6>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
         clocks("matrix only");
-        timeit("k_cross3 R=2 occ3 nt", [&] {
-            hipLaunchKernelGGL((k_cross<T, false, 2, 2, 3>), dim3(GX, (unsigned)std::min<int64_t>(nslabs, 3 * cus / GX)), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part3); }, out1, nbc);
-        timeit("k_cross3 R=2 occ3 nt prio", [&] {
+        timeit("k_cross R=2 occ3 nt", [&] {
+            hipLaunchKernelGGL((k_cross<T, false, 2, 2, 3, false>), dim3(GX, (unsigned)std::min<int64_t>(nslabs, 3 * cus / GX)), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part3); }, out1, nbc);
+        timeit("k_cross R=2 occ3 nt prio", [&] {
             hipLaunchKernelGGL((k_cross<T, false, 2, 2, 3, true>), dim3(GX, (unsigned)std::min<int64_t>(nslabs, 3 * cus / GX)), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part3); }, out1, nbc);
-        timeit("k_cross3 R=2 occ3 plain", [&] {
-            hipLaunchKernelGGL((k_cross<T, false, 0, 2, 3>), dim3(GX, (unsigned)std::min<int64_t>(nslabs, 3 * cus / GX)), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part3); }, out1, nbc);
-        timeit("k_cross3 R=2 occ4 nt", [&] {
-            hipLaunchKernelGGL((k_cross<T, false, 2, 2, 4>), dim3(GX, (unsigned)std::min<int64_t>(nslabs, 4 * cus / GX)), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part3); }, out1, nbc);
-        timeit("k_cross3 R=2 occ3 nt (2 row lanes/CU grid)", [&] {
-            hipLaunchKernelGGL((k_cross<T, false, 2, 2, 3>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
-        timeit("k_cross3 R=4 occ2 nt prio", [&] {
+        timeit("k_cross R=2 occ3 plain", [&] {
+            hipLaunchKernelGGL((k_cross<T, false, 0, 2, 3, false>), dim3(GX, (unsigned)std::min<int64_t>(nslabs, 3 * cus / GX)), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part3); }, out1, nbc);
+        timeit("k_cross R=2 occ4 nt", [&] {
+            hipLaunchKernelGGL((k_cross<T, false, 2, 2, 4, false>), dim3(GX, (unsigned)std::min<int64_t>(nslabs, 4 * cus / GX)), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part3); }, out1, nbc);
+        timeit("k_cross R=2 occ3 nt (2 row lanes/CU grid)", [&] {
+            hipLaunchKernelGGL((k_cross<T, false, 2, 2, 3, false>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
+        timeit("k_cross R=4 occ2 nt prio", [&] {
             hipLaunchKernelGGL((k_cross<T, false, 2, 4, 2, true>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
-        ok = compare("k_cross3 prio vs k_cross", out0, out1, nbc, false) && ok;
-        timeit("k_cross3 R=6 occ1 nt", [&] {
-            hipLaunchKernelGGL((k_cross<T, false, 2, 6, 1>), dim3(GX, (unsigned)std::min<int64_t>(nslabs, cus / GX)), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
+        ok = compare("k_cross R=4 occ2 nt prio vs round 2", out0, out1, nbc, false) && ok;
+        timeit("k_cross R=6 occ1 nt", [&] {
+            hipLaunchKernelGGL((k_cross<T, false, 2, 6, 1, false>), dim3(GX, (unsigned)std::min<int64_t>(nslabs, cus / GX)), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
         timeit("k_cross2 EXP loads only", [&] {
             hipLaunchKernelGGL((k_cross2<T, false, 2, 1>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
         timeit("k_cross2 EXP matrix work only", [&] {
             hipLaunchKernelGGL((k_cross2<T, false, 2, 2>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
         timeit("k_cross2 (LDS-DMA, weights)", [&] {
             hipLaunchKernelGGL((k_cross2<T, true, 0>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)w, part); }, out0, nbc);
-        timeit("k_cross3 (ring, weights)", [&] {
-            hipLaunchKernelGGL((k_cross<T, true, 0>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)w, part); }, out1, nbc);
-        ok = compare("k_cross3 weights vs k_cross2 weights", out0, out1, nbc, true) && ok;
+        timeit("k_cross PRODUCT, weights", [&] {
+            hipLaunchKernelGGL((k_cross<T, true>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)w, part); }, out1, nbc);
+        ok = compare("k_cross weights vs k_cross2 weights", out0, out1, nbc, true) && ok;
         // weighted check against a host sum on a few entries (small problems only)
         if ((double)n * p < 3e8) {
             std::vector<T> hX((size_t)ld * p), hw((size_t)ld);
