@@ -485,7 +485,13 @@ constexpr int kGcMaxSupport = 512;  // supports beyond this are not worth Gram c
 constexpr size_t kGcMaxBytes = (size_t)1 << 30;
 constexpr int64_t kGcCovWindow = 2048;      // positions one covariance-form chunk of a full pass may span
 constexpr int64_t kGcCovRefresh = 200000;   // covariance-form visits after which g is re-read from X
-constexpr int64_t kGcRowsPerNnz = 400;   // rows the problem must have per non-zero for the host-side fold to pay
+constexpr int64_t kGcRowsPerNnz = 400;   // rows the problem must have per non-zero for the HOST-side fold and re-check to pay ...
+constexpr int64_t kGcRowsPerNnzDev = 32; // ... and when the passes run on the device (round 3: g, the fold and the re-check never leave it)
+inline int64_t gc_rows_per_nnz(const cdh_handle_s* h) {
+    const GradCache& c = h->gc;
+    if (const char* e = getenv("CDH_GC_ROWS_PER_NNZ")) return std::max<int64_t>(1, atoll(e));   // experiments
+    return (c.cov && (c.d_scan || c.g.empty())) ? kGcRowsPerNnzDev : kGcRowsPerNnz;   // (before the first sizing: assume the device path)
+}
 
 // every loss and both storage types (round 3); a weighted loss only once its weights are there (they are zero until
 // cdh_set_obs_weights: every a_k would be zero and nothing could be settled)

@@ -204,7 +204,7 @@ bool gc_ready_for_cov(cdh_handle h, const int64_t* idx0, int64_t m) {
     if (!c.cov || !c.valid || !gc_applicable(h) || !c.d_G) return false;
     // the same bounds the full passes keep (gc_full_pass): the cache only pays on tall problems, and g is carried
     // through a bounded number of covariance-form updates before it is taken afresh from X
-    if (c.mode != 3 && h->x.nnz() * kGcRowsPerNnz > h->n_total) { gc_invalidate(h, false); return false; }
+    if (c.mode != 3 && h->x.nnz() * gc_rows_per_nnz(h) > h->n_total) { gc_invalidate(h, false); return false; }
     if (c.cov_since_ref > c.refresh_after && gc_rereference(h) != CDH_OK) return false;
     if (!c.moved.empty()) {
         for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return false;
@@ -609,7 +609,7 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     // Folding a moved coordinate into g is p host flops (~0.5 ns each); reading X once is n p sz bytes at
     // ~6 TB/s.  The cache only pays while nnz * p * 0.5 ns stays well under that, i.e. for n >> 400 nnz:
     // short-and-wide problems (the reference's own n = 3000, p = 5000 shape) keep the dots-only screens.
-    if (c.mode != 3 && h->x.nnz() * kGcRowsPerNnz > h->n_total) {
+    if (c.mode != 3 && h->x.nnz() * gc_rows_per_nnz(h) > h->n_total) {
         if (c.valid) gc_invalidate(h, false);
         return CDH_OK;
     }

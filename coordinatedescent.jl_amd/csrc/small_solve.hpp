@@ -39,6 +39,87 @@ __device__ __forceinline__ uint64_t small_rng_next(uint64_t& state) {
     return z ^ (z >> 31);
 }
 
+// ---- what both one-launch kernels share: the scheduler and dropzeros!, executed by ONE wave on arrays in LDS ---------------
+// (LDS operations of a wave are issued and served in order, so lane 0's store is seen by a later load of any lane of the
+// same wave; the fences only keep the compiler from moving accesses across these points)
+#define CDH_WAVE_SYNC()                                          \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
+
+// reset!(it, full) + collect(it) (atom_iterator.jl:34-37, 53-64): list[0 .. L) = the pass's visit list.  Shuffled:
+// Fisher-Yates, j_i = i + next() mod (L - i); splitmix64's state is a counter -- draw i is a function of state + (i + 1)
+// gamma alone -- so the draws are made by all lanes and only the swaps are sequential.  `draw` may alias `list`.
+__device__ __forceinline__ int wave_build_list(int lane, bool full, int randomize, int p, int nnz, uint64_t& rng, int32_t* order,
+                                               int32_t* draw, int32_t* list, const int32_t* slot2ind) {
+    const int L = full ? p : nnz;
+    if (randomize) {
+        for (int i = lane; i < L; i += 64) {
+            order[i] = i;
+            if (i + 1 < L) {
+                uint64_t st = rng + (uint64_t)i * 0x9E3779B97F4A7C15ull;
+                draw[i] = i + (int)mod64_small(small_rng_next(st), (uint32_t)(L - i));
+            }
+        }
+        if (L > 1) rng += (uint64_t)(L - 1) * 0x9E3779B97F4A7C15ull;
+        CDH_WAVE_SYNC();
+        if (lane == 0)
+            for (int i = 0; i + 1 < L; ++i) {
+                const int j = draw[i];
+                const int t = order[i]; order[i] = order[j]; order[j] = t;
+            }
+        CDH_WAVE_SYNC();
+        for (int i0 = 0; i0 < L; i0 += 64) {                  // (read everything of a group before `list`, which may be `draw`, is written)
+            const int i = i0 + lane;
+            const int v = i < L ? (full ? order[i] : slot2ind[order[i]]) : 0;
+            if (i < L) list[i] = v;
+        }
+    } else {
+        for (int i = lane; i < L; i += 64) list[i] = full ? i : slot2ind[i];
+    }
+    CDH_WAVE_SYNC();
+    return L;
+}
+
+// dropzeros!(x): swap-with-last (sparse_iterate.hpp), as a match of holes and fillers.  With m slots holding non-zeros, the
+// zero slots below m are the holes; scanning forward, each is filled by the LAST slot not yet taken that holds a non-zero --
+// the r-th hole (ascending) by the r-th non-zero slot from the end (descending), all of which lie at or beyond m.
+// Returns the new number of slots.  `holes` and `fills` are scratch of at least nnz entries.
+__device__ __forceinline__ int wave_dropzeros(int lane, int nnz, const double* beta, int32_t* slot2ind, int32_t* ind2slot,
+                                              int32_t* holes, int32_t* fills) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int m = 0;
+    for (int s0 = 0; s0 < nnz; s0 += 64) {
+        const int s = s0 + lane;
+        m += __popcll(__ballot(s < nnz && beta[slot2ind[s < nnz ? s : 0]] != 0.0));
+    }
+    if (m == nnz) return nnz;                                  // nothing to drop: the usual end of an active pass
+    int nh = 0, nf = 0;
+    for (int s0 = 0; s0 < m; s0 += 64) {
+        const int s = s0 + lane;
+        const bool hole = s < m && beta[slot2ind[s < m ? s : 0]] == 0.0;
+        const unsigned long long hm = __ballot(hole);
+        if (hole) holes[nh + __popcll(hm & below)] = s;
+        nh += __popcll(hm);
+    }
+    for (int s1 = nnz; s1 > m; s1 -= 64) {                     // chunks from the end; inside a chunk lane 0 is the last slot
+        const int s = s1 - 1 - lane;
+        const bool fil = s >= m && beta[slot2ind[s >= m ? s : m]] != 0.0;
+        const unsigned long long fm = __ballot(fil);
+        if (fil) fills[nf + __popcll(fm & below)] = s;
+        nf += __popcll(fm);
+    }
+    CDH_WAVE_SYNC();
+    // every slot that holds a zero loses its coordinate -> slot link; then the fillers move into the holes
+    for (int s = lane; s < nnz; s += 64) { const int ks = slot2ind[s]; if (beta[ks] == 0.0) ind2slot[ks] = 0; }
+    CDH_WAVE_SYNC();
+    for (int r = lane; r < nh; r += 64) { const int kf = slot2ind[fills[r]]; slot2ind[holes[r]] = kf; ind2slot[kf] = holes[r] + 1; }
+    CDH_WAVE_SYNC();
+    return m;
+}
+
 // One wave.  ga: interleaved (g_k, a_k) as k_col_dots leaves them; G: p x p, column k at G + k p; q_in: r'r (sqrt-lasso).
 // Dynamic LDS: the p-sized state (g, beta, a, omega; the visit list, the support's slots, the shuffle) and then as many
 // Gram COLUMNS as fit (ncache): a coordinate's column is kept from its first move on, so the active passes -- one step
@@ -116,30 +197,7 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
         for (int64_t iter = 0; iter < maxIter; ++iter) {
             const bool full = conv;
             const int L = full ? p : nnz;
-            // ---- reset!(it, full) + collect(it) (atom_iterator.jl:34-37, 53-64) ----
-            if (randomize) {
-                // Fisher-Yates, j_i = i + next() mod (L - i).  splitmix64's state is a counter: draw i is a function of
-                // state + (i + 1) gamma alone, so the draws are made by all lanes; only the swaps are sequential
-                for (int i = lane; i < L; i += 64) {
-                    s_order[i] = i;
-                    if (i + 1 < L) {
-                        uint64_t st = rng + (uint64_t)i * 0x9E3779B97F4A7C15ull;
-                        s_draw[i] = i + (int)mod64_small(small_rng_next(st), (uint32_t)(L - i));
-                    }
-                }
-                if (L > 1) rng += (uint64_t)(L - 1) * 0x9E3779B97F4A7C15ull;
-                __syncthreads();
-                if (lane == 0)
-                    for (int i = 0; i + 1 < L; ++i) {
-                        const int j = s_draw[i];
-                        const int t = s_order[i]; s_order[i] = s_order[j]; s_order[j] = t;
-                    }
-                __syncthreads();
-                for (int i = lane; i < L; i += 64) s_list[i] = full ? s_order[i] : s_slot2ind[s_order[i]];
-            } else {
-                for (int i = lane; i < L; i += 64) s_list[i] = full ? i : s_slot2ind[i];
-            }
-            __syncthreads();
+            (void)wave_build_list(lane, full, randomize, p, nnz, rng, s_order, s_draw, s_list, s_slot2ind);
             // ---- _cdPass! (coordinate_descent.jl:94-110), 64 positions of the visit list at a time: lane l owns position
             // c0 + l for the whole chunk and keeps its coordinate's a, omega, beta, slot links AND gradient in registers.
             // A step evaluates every lane's visit against its current g, takes the first lane (from `done` on) that
@@ -244,41 +302,7 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
                 }
                 __syncthreads();                                            // s_g, s_beta and the slot links as the next chunk / pass reads them
             }
-            // ---- dropzeros!(x): swap-with-last (sparse_iterate.hpp), as a match of holes and fillers.  With m slots holding
-            // non-zeros, the zero slots below m are the holes; scanning forward, each is filled by the LAST slot not yet
-            // taken that holds a non-zero -- the r-th hole (ascending) by the r-th non-zero slot from the end (descending),
-            // all of which lie at or beyond m ----
-            {
-                int m = 0;
-                for (int s0 = 0; s0 < nnz; s0 += 64) {
-                    const int s = s0 + lane;
-                    m += __popcll(__ballot(s < nnz && s_beta[s_slot2ind[s < nnz ? s : 0]] != 0.0));
-                }
-                if (m < nnz) {                                              // (nothing to drop: the usual end of an active pass)
-                // holes, ascending -> s_order[r];  fillers, descending -> s_draw[r]
-                int nh = 0, nf = 0;
-                for (int s0 = 0; s0 < m; s0 += 64) {
-                    const int s = s0 + lane;
-                    const bool hole = s < m && s_beta[s_slot2ind[s < m ? s : 0]] == 0.0;
-                    const unsigned long long hm = __ballot(hole);
-                    if (hole) s_order[nh + __popcll(hm & below)] = s;
-                    nh += __popcll(hm);
-                }
-                for (int s1 = nnz; s1 > m; s1 -= 64) {                     // chunks from the end; inside a chunk lane 0 is the last slot
-                    const int s = s1 - 1 - lane;
-                    const bool fil = s >= m && s_beta[s_slot2ind[s >= m ? s : m]] != 0.0;
-                    const unsigned long long fm = __ballot(fil);
-                    if (fil) s_draw[nf + __popcll(fm & below)] = s;
-                    nf += __popcll(fm);
-                }
-                __syncthreads();
-                // every slot that holds a zero loses its coordinate -> slot link; then the fillers move into the holes
-                for (int s = lane; s < nnz; s += 64) { const int ks = s_slot2ind[s]; if (s_beta[ks] == 0.0) s_ind2slot[ks] = 0; }
-                __syncthreads();
-                for (int r = lane; r < nh; r += 64) { const int kf = s_slot2ind[s_draw[r]]; s_slot2ind[s_order[r]] = kf; s_ind2slot[kf] = s_order[r] + 1; }
-                nnz = m;
-                }
-            }
+            nnz = wave_dropzeros(lane, nnz, s_beta, s_slot2ind, s_ind2slot, s_order, s_draw);
             __syncthreads();
             passes += 1; visits += L; lastH = maxH;
             if (full) full_passes += 1;
@@ -317,16 +341,23 @@ inline bool small_applicable(const cdh_handle_s* h, const cdh_options* o) {
            h->gc.mode != 3 /* tests force the gradient cache's own path with mode 3 */ && (h->loss != CDH_WLS || h->has_w) &&
            o->numSteps + 1 <= kSmallMaxLam && o->numSteps >= 1;
 }
+// (Measured and dropped, round 3: the same state machine in RESIDUAL form for short columns and many coordinates -- the
+// reference's benchmark itself is n = 3000, p = 5000, where no Gram matrix fits -- as ONE workgroup with the residual in
+// registers and the next columns prefetched into a ring of registers.  Correct (47 parity cases), but every column has to come
+// through one CU, and one CU draws ~25 GB/s from HBM: 24 KB per visit = 1.2 us per visit at best, against 0.65 us per
+// visit for the streamed sweep that uses the whole chip (0.88 s against 0.53 s on cd_bench.jl's dense lambda = 0.001 solve;
+// 1.9 s with four waves per SIMD repeating the scalar update).  A one-launch solve pays only while what a visit reads stays on
+// chip -- which is what the Gram form's limits say.)
 
-int32_t small_prepare(cdh_handle h) {     // buffers + the full Gram matrix of the resident X
+int32_t small_prepare(cdh_handle h) {     // buffers, X'y and diag(G) of the current y, the full Gram matrix of the resident X
     SmallPath& sp = h->small;
     GradCache& c = h->gc;
-    if (!sp.d_G) {
+    if (!sp.d_io) {
         CHK(gc_size(h));                  // k_cross's scratch (d_cross, d_cross_part, d_cols) is the gradient cache's
         if (!c.d_cross) { sp.enabled = false; return CDH_OK; }
         bool fits = hipMalloc((void**)&sp.d_G, sizeof(double) * (size_t)h->p * (size_t)h->p) == hipSuccess &&
-                    // one block for everything that crosses the bus per solve: [SmallCtl][support: p int32][beta: p doubles]
                     hipMalloc((void**)&sp.d_ca, sizeof(double) * (2 * (size_t)h->p + 1)) == hipSuccess &&
+                    // one block for everything that crosses the bus per solve: [SmallCtl][support: p int32][beta: p doubles]
                     hipMalloc((void**)&sp.d_io, small_io_bytes(h->p)) == hipSuccess &&
                     hipHostMalloc((void**)&sp.h_io, small_io_bytes(h->p)) == hipSuccess;
         if (!fits) { (void)hipGetLastError(); sp.enabled = false; return CDH_OK; }

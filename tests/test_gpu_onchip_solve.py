@@ -237,6 +237,7 @@ def test_new_columns_new_y_and_the_size_limits():
         x = cd.SparseIterate(p)
         cd.coordinateDescent_(x, f, cd.ProxL1(0.2), cd.CDOptions(**o))
         assert f.onchip_stats() == {"solves": 0, "gram_matrices": 0}
+        np.testing.assert_allclose(x.dense(), O.lasso(X, Y, 0.2, None, O.CDOptions(**o)).x.dense(), rtol=0, atol=BETA_TOL)
         f.close()
 
 
@@ -259,3 +260,4 @@ def test_zero_column_fp32_storage_and_maxiter():
     np.testing.assert_allclose(x.dense(), want, rtol=0, atol=3e-4)      # fp32 storage against the fp64 oracle
     assert f32.onchip_stats()["solves"] == 1 and f32.r.dtype == np.float32
     f32.close()
+
