@@ -200,7 +200,7 @@ struct cdh_handle_s {
     bool has_omega = false, has_w = false, y_set = false;
     std::vector<double> h_omega;  // host copy of the penalty weights (thresholds, objective)
     cdh::SupportList x;
-    int mode = CDH_SWEEP_BLOCK, blockB = 32;   // the fastest width on one GPU; cdh_set_sweep_mode changes it
+    int mode = CDH_SWEEP_BLOCK, blockB = 32;   // the default (cdh_create: 64 on short fp64 columns); cdh_set_sweep_mode changes it
     bool use_graph = false;
     int screening = 1;            // 0 never, 1 the solves' full passes over sparse iterates, 2 cdh_pass too
     bool reuse_residual = false;  // warm starts skip initialize! when r is known to match beta
@@ -680,12 +680,20 @@ template <typename T, int NG> int32_t launch_gram_chunk(cdh_handle h, int m) {
     // width; with short chunks also -10 % for B = 32 at 6.25e5 .. 1.25e6 rows and neutral for
     // B = 64.  B = 16 takes it on long columns only.  fp32 B = 64 would spill: fragment path.
     const bool use_lt = (h->lt == 1 || (h->lt == 2 && (NG >= 2 || h->n >= 2000000))) && !(NG == 4 && sizeof(T) == 4);
-    const int G = NGgrid(h, NG, use_lt);
-    if ((size_t)G * R::N > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partial buffer too small for this grid");
+    int G = NGgrid(h, NG, use_lt);
     // short columns (a launch is fewer than kShortRounds rounds of 64-vector chunks): chunks of
     // one sub-chunk, so a partly filled last round costs a quarter (B = 64) or half (B = 32) as much
     const int64_t rounds64 = ((h->nvec + 63) / 64) / ((int64_t)G * kGramWaves);
     const bool short_chunks = use_lt && (h->ks == 1 || (h->ks == 0 && rounds64 < kShortRounds));
+    // ... and as many blocks as there are chunks of THAT length to hand out, four per block (round 3: the grid was sized for
+    // 64-vector chunks, which at 24 KB columns -- benchmark/cd_bench.jl's n = 3000 -- left 6 blocks to walk 94 short chunks,
+    // four apiece and one after the other: 31 us per launch whatever it read)
+    {
+        const int64_t cvn = use_lt ? (int64_t)(64 / NG) * (short_chunks ? 1 : NG) : 64;
+        const int64_t nchunks = (h->nvec + cvn - 1) / cvn;
+        G = balanced_grid((nchunks + kGramWaves - 1) / kGramWaves, (int64_t)h->cus * gram_blocks_per_cu(h, NG, use_lt));
+    }
+    if ((size_t)G * R::N > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partial buffer too small for this grid");
     int nprev = 0;
     for (int pos0 = 0; pos0 < m; pos0 += B) {
         const int nb = std::min(B, m - pos0);
@@ -1068,6 +1076,11 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
     h->ld = round_up(n_local, 32);            // every column starts 128/256-B aligned
     h->nvec = round_up(n_local, NV) / NV;     // pad rows [n, ld) are zero in X, y, r, w
     h->cap = std::max<int64_t>(p, 4096);
+    // The default sweep width: B = 32 streams fastest per visit on long columns; on SHORT ones (the grid is not even full:
+    // fewer than 512 blocks x 4 waves x 64 vectors) a block of visits costs three launches whatever it reads, and B = 64
+    // halves them (benchmark/cd_bench.jl's dense solve at n = 3000: 0.40 s at B = 32, 0.26 s at B = 64).  fp32 storage has
+    // no LDS-transposed B = 64 kernel and keeps 32.
+    if (dtype == CDH_F64 && n_local < (int64_t)512 * kGramWaves * 64 * 2) h->blockB = 64;
     h->x.resize(p);
     h->r_pending.assign((size_t)p, 0.0);
     h->r_in_pending.assign((size_t)p, 0);

@@ -65,7 +65,8 @@ typedef enum cdh_loss { CDH_LS = 0, CDH_SQRT = 1, CDH_WLS = 2 } cdh_loss;
  *                    all-reduce per block.  B in {2, 4, 8, 16, 32, 64}; with
  *                    observation weights (CDH_WLS) B >= 16, narrower widths then
  *                    run the per-coordinate sweep.
- * A new handle sweeps in blocks of B = 32, the fastest width on one GPU. */
+ * A new handle sweeps in blocks of B = 32, the fastest width on one GPU for long columns (B = 64 for fp64 columns of
+ * fewer than 262 144 rows, where a block of visits costs its three launches whatever it reads). */
 typedef enum cdh_sweep_mode { CDH_SWEEP_COORD = 0, CDH_SWEEP_BLOCK = 1 } cdh_sweep_mode;
 
 /* CDOptions (utils.jl:7-20), field for field, + the seed of the substitute RNG
