@@ -121,6 +121,7 @@ struct GradCache {
     double yy = 0.0;                      // y'y over all shards (fp32 certificate margin), valid while yy_ok
     bool yy_ok = false;
     int64_t n_dev_passes = 0;
+    int inject_rollback = 0, inject_count = 0;   // env CDH_GC_INJECT_ROLLBACK (tests)
     int64_t dev_slots_cap = 0, dev_slots = 0;   // columns the device store can hold / holds
     int64_t cov_since_ref = 0;      // covariance-form visits since g was last taken from X itself
     int64_t refresh_after = 0;      // ... after which it is (kGcCovRefresh; env CDH_GC_REFRESH for tests)
@@ -1100,6 +1101,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->gc.mode = std::max(0, std::min(3, env_int("CDH_GRADIENT_CACHE", 1)));
         h->gc.cov = env_int("CDH_GC_COV", 1) != 0;
         h->small.enabled = env_int("CDH_SMALL_PATH", 1) != 0;
+        h->gc.inject_rollback = std::max(0, env_int("CDH_GC_INJECT_ROLLBACK", 0));
         h->gc.refresh_after = std::max(1, env_int("CDH_GC_REFRESH", (int)kGcCovRefresh));
         const int step_per_cu = std::max(1, env_int("CDH_STEP_GRID_PER_CU", 8));
         const int block_per_cu = std::max(1, std::min(kBlockGridPerCU, env_int("CDH_BLOCK_GRID_PER_CU", 3)));

@@ -1013,6 +1013,41 @@ def test_gradient_cache_keeps_g_on_the_device_and_reports_its_drift():
     f.close()
 
 
+@pytest.mark.parametrize("loss", ["ls", "wl1", "sqrt", "wls"])
+@pytest.mark.parametrize("every", [1, 3])
+def test_device_passes_that_are_undone_leave_no_trace(monkeypatch, loss, every):
+    """A device-side pass whose re-check fails is undone (g and beta from the scan's snapshot) and walked again in
+    windows.  CDH_GC_INJECT_ROLLBACK declares every N-th device pass failed AFTER it ran -- every one of them, or one in
+    three -- so the undo is exercised wherever the cache works, not only where a certificate happens to break: same beta as
+    the oracle at every lambda, same support order, same pass counts; with N = 1 no pass completes on the device at all."""
+    monkeypatch.setenv("CDH_GC_INJECT_ROLLBACK", str(every))
+    rng, X, Y = _problem(64, 4000, 560, 12, noise=1.0)
+    X *= rng.uniform(0.5, 2.0, size=560)
+    om = (rng.random(560) + 0.5) if loss == "wl1" else None
+    w = rng.random(4000) + 0.5
+    top = 3.4 if loss == "sqrt" else 0.3
+    lams = np.exp(np.linspace(np.log(top), np.log((0.6 if loss == "sqrt" else 0.1) * top), 10))
+    o = dict(maxIter=3000, optTol=1e-10, randomize=(every == 3), seed=21)
+    if loss == "sqrt":
+        f, fo = cd.CDSqrtLassoLoss(Y, X), O.CDSqrtLassoLoss(Y, X)
+    elif loss == "wls":
+        f, fo = cd.CDWeightedLSLoss(Y, X, w), O.CDWeightedLSLoss(Y, X, w)
+    else:
+        f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+    f.set_gradient_cache(3)
+    x, xo = cd.SparseIterate(560), O.SparseIterate(560)
+    for lam in lams:
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(**o))
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam, om), O.CDOptions(**o))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"], (loss, every, lam)
+    np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-9)
+    cs = f.cache_stats()
+    assert cs["passes"] >= 8 and cs["rollbacks"] >= (cs["passes"] - 2 if every == 1 else 2), cs
+    assert (cs["device_passes"] == 0) if every == 1 else (cs["device_passes"] >= 3), cs
+    f.close()
+
+
 def test_gradient_cache_follows_new_iterates_new_y_and_cold_starts():
     """What invalidates or shifts the cached gradient: a warm start from a DIFFERENT x (the difference is
     folded in as moves), a cold start (x zeroed, 51 continuation solves -- all served from the cache), a
