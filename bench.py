@@ -391,11 +391,19 @@ def main():
 
     f, bstar = cd.CDLeastSquaresLoss.generate(n_local, a.cols, seed=123, s=a.planted, noise=a.noise, dtype=dtype,
                                               device=device, n_total=a.rows, row_offset=row0)
-    exchange = "rccl"
+    exchange, exchange_fallback = "rccl", None
     if a.no_rccl:
         exchange = "none(test-only)"
     else:
-        sharded.connect(f, cp)
+        # the communicator is built AND probed (exact sums of three records) before anything is timed over it.  A run
+        # whose RCCL cannot be built or sums wrongly still measures the sharded sweep -- over the host-staged exchange,
+        # which needs nothing from the interconnect and is far slower -- and the line says so instead of dying
+        rccl_ok, why = sharded.connect_checked(f, cp)
+        if not rccl_ok:
+            f.comm_drop()
+            sharded.connect_host(f, cp)
+            exchange, exchange_fallback = "host(gloo)", why
+            a.exchange, a.graph = "rccl", False      # no direct-exchange trial on top of a machine RCCL failed on; no graphs
     if cp.world > 1 and a.exchange == "p2p" and sharded.connect_p2p(f, cp):
         exchange = "p2p"
     if a.block is None:
@@ -508,7 +516,7 @@ def main():
                        "sweep_mode": a.mode + (str(a.block) if a.mode == "block" else ""), "graph": bool(a.graph),
                        "parallelism": f"rows{cp.world}",
                        "exchange": exchange if (cp.world > 1 or st["rccl_calls"] > 0) else None,
-                       "moved_per_sweep": moved, "last_maxH": maxh},
+                       "moved_per_sweep": moved, "last_maxH": maxh, "beta_abs_sum": float(np.abs(beta_timed).sum())},
             # what the exchange itself reports: the communicator's rank count (ncclCommCount) and how many
             # all-reduces went through each transport since the handle was created (rank 0)
             "exchange_stats": st,
@@ -526,6 +534,8 @@ def main():
         }
 
     res = result(exchange, dt, maxh, ev_ms, launches, alg_bytes)
+    if exchange_fallback:
+        res["exchange_fallback"] = {"wanted": "rccl", "used": exchange, "why": exchange_fallback}
     if sparse is not None:
         res["sparse_regime"] = sparse
     if exch_us:

@@ -143,6 +143,7 @@ def lib():
         "cdh_set_screening": [vp, i32],
         "cdh_comm_unique_id": [vp],
         "cdh_comm_init": [vp, vp, i32, i32],
+        "cdh_comm_drop": [vp],
         "cdh_p2p_local_handle": [vp, vp],
         "cdh_p2p_connect": [vp, vp, i32, i32],
         "cdh_p2p_enable": [vp, i32],

@@ -331,6 +331,10 @@ class _HipLoss(CoordinateDifferentiableFunction):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         check(self._L.cdh_comm_init(self._h, buf, int(rank), int(nranks)), self._h)
 
+    def comm_drop(self):
+        """Give the RCCL communicator up so that another exchange can be installed (cdh_comm_drop)."""
+        check(self._L.cdh_comm_drop(self._h), self._h)
+
     def p2p_local_handle(self) -> bytes:
         buf = C.create_string_buffer(64)
         check(self._L.cdh_p2p_local_handle(self._h, buf), self._h)

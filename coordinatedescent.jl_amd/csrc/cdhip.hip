@@ -37,6 +37,7 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     void* CommInitRank = nullptr;  // (ncclComm_t*, int nranks, ncclUniqueId by value, int rank)
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr;
     int (*CommCount)(void*, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -56,6 +57,7 @@ bool load_rccl(std::string& err) {
     g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
     g_rccl.CommInitRank = dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.CommAbort = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommAbort");
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(
         g_rccl.lib, "ncclAllReduce");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
@@ -1757,6 +1759,19 @@ int32_t cdh_comm_init(cdh_handle h, const void* id_128_bytes, int32_t rank, int3
         return CDH_RCCL_ERROR;
     }
     h->rank = rank; h->nranks = nranks;
+    return CDH_OK;
+}
+
+int32_t cdh_comm_drop(cdh_handle h) {
+    NEED_H(h);
+    if (!h->comm) return CDH_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);   // captured passes hold the communicator's all-reduces
+    h->graphs.clear();
+    if (g_rccl.CommAbort) g_rccl.CommAbort(h->comm); else if (g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr;
+    if (h->nranks > 1 && !h->p2p_on && !h->host_fn) h->lost_exchange = true;
     return CDH_OK;
 }
 

@@ -116,6 +116,63 @@ def connect(loss, cp: ControlPlane):
     return loss
 
 
+def connect_checked(loss, cp: ControlPlane, unique_id=None) -> tuple[bool, str]:
+    """connect() for a caller that can go on without RCCL (bench.py): builds the communicator, sums three probe
+    records through it and compares them with the exact expected sums.  Returns (True, "") only if every stage
+    succeeded on EVERY rank; otherwise (False, reason) -- the reason of the lowest rank that failed -- and the
+    caller picks another exchange (connect_host).  Collective: every rank goes through the same sequence of
+    control-plane collectives whatever fails locally, so one rank's failure cannot leave the others waiting.
+    What it cannot catch is a communicator whose construction never returns.  `unique_id` (tests): a callable
+    standing in for cdh_comm_unique_id on rank 0."""
+    import numpy as np
+    from . import _lib
+    if cp.world == 1:
+        return True, ""
+
+    def agree(ok: bool, why: str) -> tuple[bool, str]:
+        if cp.sum_over_ranks(1.0 if ok else 0.0) == cp.world:
+            return True, ""
+        blob = cp.all_gather_bytes((b"" if ok else (why or "failed").encode()[:200]).ljust(200, b"\0"))
+        for q in range(cp.world):
+            msg = blob[200 * q:200 * (q + 1)].rstrip(b"\0").decode(errors="replace")
+            if msg:
+                return False, f"rank {q}: {msg}"
+        return False, "a rank failed without saying why"
+
+    ok, why, uid = True, "", bytes(128)
+    if cp.rank == 0:
+        try:
+            if unique_id is not None:
+                uid = bytes(unique_id())
+            else:
+                buf = C.create_string_buffer(128)
+                _lib.check(_lib.lib().cdh_comm_unique_id(buf), None)
+                uid = buf.raw
+        except Exception as e:
+            ok, why = False, f"cdh_comm_unique_id: {e}"
+    uid = cp.broadcast_bytes(uid if cp.rank == 0 else None, 128, src=0)
+    ok, why = agree(ok, why)
+    if not ok:
+        return False, why
+    try:
+        loss.comm_init(uid, cp.rank, cp.world)
+    except Exception as e:
+        ok, why = False, f"cdh_comm_init: {e}"
+    ok, why = agree(ok, why)
+    if not ok:
+        return False, why
+    try:
+        w, base = cp.world, np.arange(801, dtype=np.float64)
+        for rep in range(3):
+            got = loss.exchange_probe((cp.rank + 1) * (base + rep) + 0.25 * cp.rank)
+            want = (w * (w + 1) / 2) * (base + rep) + 0.25 * (w * (w - 1) / 2)
+            if ok and not np.array_equal(got, want):     # (no early exit: the peers are in the next all-reduce)
+                ok, why = False, f"probe record {rep}: sums over the communicator are wrong"
+    except Exception as e:
+        ok, why = False, f"cdh_exchange_probe: {e}"
+    return agree(ok, why)
+
+
 def connect_host(loss, cp: ControlPlane):
     """Row-shard exchange over the control plane itself (cdh_set_host_exchange): every all-reduce of
     the sweep is staged through pinned host memory and summed by torch.distributed (gloo).  Far slower

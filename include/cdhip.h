@@ -249,6 +249,11 @@ int32_t cdh_set_use_graph(cdh_handle h, int32_t on);
  * 128 bytes (any transport), every rank calls cdh_comm_init. */
 int32_t cdh_comm_unique_id(void *out_128_bytes);
 int32_t cdh_comm_init(cdh_handle h, const void *id_128_bytes, int32_t rank, int32_t nranks);
+/* Give the communicator up (ncclCommAbort) so that another exchange can be installed on the handle -- for a
+ * caller that found it unusable (wrong sums from cdh_exchange_probe).  The shard stays a shard: until
+ * cdh_set_host_exchange / the direct exchange takes over, every exchange on it refuses rather than sum
+ * local rows only.  A handle that never had a communicator: no-op. */
+int32_t cdh_comm_drop(cdh_handle h);
 /* Optional direct exchange for the short per-block records (<= 2688 doubles) of a row-sharded
  * sweep: every rank stores its record into an IPC-mapped inbox on every peer and sums the
  * sources in rank order (one hop over the xGMI mesh, no ring).  OFF unless connected AND

@@ -549,6 +549,40 @@ def test_bench_gpus_2_without_a_launcher_two_ranks_one_gpu():
     assert abs(ja["config"]["last_maxH"] - jb["config"]["last_maxH"]) <= 1e-9 * abs(jb["config"]["last_maxH"])
 
 
+def test_bench_two_ranks_when_rccl_cannot_serve_them_still_measures_the_sharded_sweep():
+    """`python bench.py --gpus 2` exactly as the driver would start it, on a box with ONE card: RCCL refuses two ranks on
+    one device (or, should this build accept them, serves them).  Either way there is one result line with n_gpus == 2 whose
+    sweep equals the one-rank sweep: over RCCL if the communicator came up and summed the probe records exactly, otherwise
+    over the host-staged exchange with the reason on the line (sharded.connect_checked + cdh_comm_drop)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = ["--steps", "2", "--warmup", "1", "--rows", "300000", "--cols", "96", "--planted", "10",
+           "--no-cpu-baseline", "--no-sparse", "--block", "16", "--no-exchange-trial"]
+    a = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + cmd,
+                       capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert a.returncode == 0, (a.stdout[-1500:], a.stderr[-3000:])
+    got = [l for l in a.stdout.splitlines() if l.strip()]
+    assert len(got) == 1 and got[0].startswith("{"), got
+    ja = json.loads(got[0])
+    assert ja["n_gpus"] == 2 and ja["exchange_stats"]["nranks"] == 2
+    if "exchange_fallback" in ja:
+        fb = ja["exchange_fallback"]
+        assert fb["used"] == "host(gloo)" == ja["config"]["exchange"] and fb["why"].startswith("rank ")
+        assert ja["exchange_stats"]["host_calls"] > 0 and ja["exchange_stats"]["rccl_calls"] == 0
+    else:
+        assert ja["config"]["exchange"] == "rccl" and ja["exchange_stats"]["rccl_calls"] > 0
+    b = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + cmd,
+                       capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert b.returncode == 0, b.stderr[-2000:]
+    jb = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
+    assert ja["config"]["moved_per_sweep"] == jb["config"]["moved_per_sweep"]
+    assert abs(ja["config"]["last_maxH"] - jb["config"]["last_maxH"]) <= 1e-9 * abs(jb["config"]["last_maxH"])
+    assert abs(ja["config"]["beta_abs_sum"] - jb["config"]["beta_abs_sum"]) <= 1e-9 * jb["config"]["beta_abs_sum"]
+
+
 def test_bench_a_direct_exchange_probe_that_dies_costs_nothing():
     """--exchange auto (the default): the direct exchange meets the machine in child processes first.  Here every
     probe dies on the spot (os._exit, the stand-in for a GPU fault in a transport that has never run on this

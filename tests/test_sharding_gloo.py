@@ -100,3 +100,70 @@ def test_two_rank_gloo_sharded_solve_matches_oracle(tmp_path):
     O.coordinateDescent_(xo, O.CDLeastSquaresLoss(y, X), O.ProxL1(lam),
                          O.CDOptions(maxIter=500, optTol=1e-13, randomize=False))
     np.testing.assert_allclose(betas[0], xo.dense(), rtol=0, atol=1e-10)
+
+
+class _FakeShard:
+    """Stands in for a loss handle in connect_checked: what matters here is the sequence of control-plane
+    collectives when a stage fails on ONE rank only (no rank may be left waiting in a collective)."""
+
+    def __init__(self, rank, world, fail_init_on=None, wrong_sums_on=None, dist=None):
+        self.rank, self.world, self.fail_init_on, self.wrong_sums_on, self.dist = rank, world, fail_init_on, wrong_sums_on, dist
+        self.uid = None
+
+    def comm_init(self, uid, rank, world):
+        self.uid = uid
+        if self.fail_init_on == rank:
+            raise RuntimeError("ncclCommInitRank failed: unhandled system error")
+
+    def exchange_probe(self, values):
+        t = torch.from_numpy(np.array(values, dtype=np.float64))
+        self.dist.all_reduce(t)
+        out = t.numpy().copy()
+        if self.wrong_sums_on == self.rank:
+            out[7] += 1.0
+        return out
+
+
+def _connect_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from importlib import import_module
+    import coordinatedescent_jl_amd  # noqa: F401
+    sharded = import_module("coordinatedescent_jl_amd.sharded")
+    cp = sharded.ControlPlane(backend="gloo")
+    uid = lambda: bytes(range(128))      # noqa: E731
+
+    def boom():
+        raise OSError("dlopen librccl failed")
+
+    got = []
+    good = _FakeShard(rank, world, dist=dist)
+    got.append(sharded.connect_checked(good, cp, unique_id=uid))
+    assert good.uid == bytes(range(128))                       # every rank received rank 0's id
+    got.append(sharded.connect_checked(_FakeShard(rank, world, dist=dist), cp, unique_id=boom))
+    got.append(sharded.connect_checked(_FakeShard(rank, world, fail_init_on=1, dist=dist), cp, unique_id=uid))
+    got.append(sharded.connect_checked(_FakeShard(rank, world, wrong_sums_on=0, dist=dist), cp, unique_id=uid))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, got)
+    if rank == 0:
+        import json
+        with open(out, "w") as fh:
+            json.dump(gathered, fh)
+    cp.barrier()
+    cp.shutdown()
+
+
+def test_checked_connect_agrees_on_every_rank_whatever_fails_locally(tmp_path):
+    """bench.py's RCCL bring-up (sharded.connect_checked): a failure on one rank at any stage -- no unique id, no
+    communicator, wrong probe sums -- must come back as the SAME (False, reason) on every rank, with nobody left
+    waiting, so that all ranks switch to the host-staged exchange together."""
+    import json
+    world, out = 2, str(tmp_path / "connect.json")
+    mp.spawn(_connect_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0, r1 = json.load(open(out))
+    assert r0 == r1
+    assert r0[0] == [True, ""]
+    assert r0[1][0] is False and r0[1][1].startswith("rank 0: cdh_comm_unique_id:") and "dlopen" in r0[1][1]
+    assert r0[2][0] is False and r0[2][1].startswith("rank 1: cdh_comm_init:")
+    assert r0[3][0] is False and r0[3][1].startswith("rank 0: probe record 0")
