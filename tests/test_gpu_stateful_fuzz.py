@@ -222,6 +222,71 @@ def test_random_call_sequences_on_one_handle(seed, monkeypatch):
     f.close()
 
 
+@pytest.mark.parametrize("seed", range(max(8, N_SEQ // 3)))
+def test_random_call_sequences_on_one_fp32_handle(seed, monkeypatch):
+    """The same idea on fp32 storage (BASELINE.json configs[4]'s dtype): the oracle computes in fp64 on the fp32-rounded data,
+    so the bar is the declared fp32 one (3e-4 on beta, as tests/test_gpu_parity.py::test_fp32_against_fp64_oracle) and the
+    discrete outcomes (pass counts, slot order) are not compared; what a stale Gram column, gradient or residual would do to
+    beta is orders of magnitude above that bar."""
+    rng = np.random.default_rng(93000 + seed)
+    p = int(rng.integers(8, 200))
+    n = int(rng.integers(40 * p, 70 * p)) if rng.integers(0, 2) and p < 100 else int(rng.integers(2 * p, 8 * p + 40))
+    s = int(rng.integers(1, min(8, p) + 1))
+    monkeypatch.setenv("CDH_SMALL_PATH", str(int(rng.integers(0, 2))))
+    if rng.integers(0, 3) == 0:
+        monkeypatch.setenv("CDH_GC_REFRESH", str(int(rng.integers(20, 400))))
+    if rng.integers(0, 3) == 0:
+        monkeypatch.setenv("CDH_GC_INJECT_ROLLBACK", str(int(rng.integers(1, 4))))
+    X = np.asfortranarray((rng.standard_normal((n, p)) * rng.uniform(0.5, 2.0, size=p)).astype(np.float32))
+    Y = (X[:, :s].astype(np.float64) @ rng.standard_normal(s) + rng.uniform(0.5, 2.0) * rng.standard_normal(n)).astype(np.float32)
+    log = [f"fp32 seed={seed} n={n} p={p}"]
+    f = cd.CDLeastSquaresLoss(Y, X)
+    assert f.r.dtype == np.float32
+    f.set_gradient_cache(int(rng.choice([0, 1, 2, 3, 3])))
+    f.set_sweep_mode(["coord", "block"][int(rng.integers(0, 2))], int(rng.choice([2, 8, 16, 32])))
+    x, om = cd.SparseIterate(p), None
+    for step in range(int(rng.integers(5, 10))):
+        op = int(rng.integers(0, 8))
+        X64, Y64 = X.astype(np.float64), Y.astype(np.float64)
+        if op <= 3:
+            top = float(np.max(np.abs(X64.T @ Y64) / (om if om is not None else 1.0))) / n
+            lam = top * float(rng.uniform(0.15, 0.9))
+            warm = bool(rng.integers(0, 4) > 0)
+            log.append(f"solve lam={lam:.5g} warm={warm}")
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(maxIter=3000, optTol=1e-7, randomize=False, warmStart=warm,
+                                                                          numSteps=int(rng.integers(2, 8))))
+            xo = O.SparseIterate(p)
+            O.coordinateDescent_(xo, O.CDLeastSquaresLoss(Y64, np.asfortranarray(X64)), O.ProxL1(lam, om),
+                                 O.CDOptions(maxIter=5000, optTol=1e-11, randomize=False))
+            want = xo.dense()
+            np.testing.assert_allclose(x.dense(), want, rtol=0, atol=3e-4 * max(1.0, float(np.max(np.abs(want)))), err_msg="\n".join(log))
+        elif op == 4:
+            log.append("residual")
+            np.testing.assert_allclose(f.r, Y64 - X64 @ x.dense(), rtol=0, atol=2e-4 * max(1.0, float(np.max(np.abs(Y64)))),
+                                       err_msg="\n".join(log))
+        elif op == 5:
+            om = rng.uniform(0.5, 2.0, size=p) if rng.integers(0, 3) else None
+            log.append("new omega" if om is not None else "omega dropped")
+        elif op == 6:
+            Y = (X[:, :s].astype(np.float64) @ rng.standard_normal(s) + rng.uniform(0.5, 2.0) * rng.standard_normal(n)).astype(np.float32)
+            yc = np.ascontiguousarray(Y)
+            cd._lib.check(f._L.cdh_set_y(f._h, yc.ctypes.data), f._h)
+            cd.initialize_(f, x)
+            log.append("new y")
+        else:
+            j0 = int(rng.integers(0, p))
+            nc = int(rng.integers(1, min(p - j0, 10) + 1))
+            X[:, j0:j0 + nc] = (rng.standard_normal((n, nc)) * rng.uniform(0.5, 2.0, size=nc)).astype(np.float32)
+            blk = np.asfortranarray(X[:, j0:j0 + nc])
+            cd._lib.check(f._L.cdh_set_X_cols(f._h, j0, nc, blk.ctypes.data, n), f._h)
+            cd.initialize_(f, x)
+            log.append(f"columns {j0}..{j0 + nc - 1} replaced")
+        _switch_paths(rng, f, log)
+    for k, v in dict(f.cache_stats(), onchip_solves=f.onchip_stats()["solves"]).items():
+        REACHED["fp32_" + k] = REACHED.get("fp32_" + k, 0) + int(v)
+    f.close()
+
+
 def test_the_sequences_reached_the_paths_that_carry_state():
     """The point of the module is state carried across calls: the run must have gone through the one-launch solve, cache
     passes served from carried gradients (on the device and by the windowed walk), covariance-form visits with the residual
@@ -234,5 +299,7 @@ def test_the_sequences_reached_the_paths_that_carry_state():
         pytest.skip("fewer than 24 sequences ran in this process")
     for key in ("onchip_solves", "passes", "device_passes", "settled_visits", "covariance_visits", "residual_catchups",
                 "gram_batches", "reference_passes", "rollbacks"):
+        assert REACHED.get(key, 0) > 0, (key, REACHED)
+    for key in ("fp32_onchip_solves", "fp32_passes", "fp32_covariance_visits", "fp32_gram_batches"):
         assert REACHED.get(key, 0) > 0, (key, REACHED)
     assert REACHED.get("threshold_crossings", 0) <= max(1, REACHED["solves"] // 50), REACHED
