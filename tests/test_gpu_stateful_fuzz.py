@@ -27,6 +27,21 @@ N_SEQ = int(os.environ.get("CDH_FUZZ_STATEFUL", "48"))
 REACHED = {}                 # what the sequences of this run went through, summed (checked by the last test of the module)
 
 
+class Whole:
+    """How a sequence reaches its data: here the whole problem in one process; tests/stateful_fuzz_worker.py substitutes a
+    row shard per rank (same calls, same checks: beta, the scalars and the support are replicated on every rank)."""
+    sharded = False
+
+    def rows(self, n):
+        return slice(0, n)
+
+    def make(self, cls, n, y, X, *extra):
+        return cls(y, X, *extra)
+
+    def check_replicas(self, x, log):
+        pass
+
+
 def _switch_paths(rng, f, log):
     """A random change of the per-handle decisions; none of them may change an iterate."""
     what = int(rng.integers(0, 6))
@@ -64,6 +79,10 @@ def _check_iterates(x, xo, log, strict_order=True):
 
 @pytest.mark.parametrize("seed", range(N_SEQ))
 def test_random_call_sequences_on_one_handle(seed, monkeypatch):
+    run_sequence(seed, monkeypatch.setenv, Whole())
+
+
+def run_sequence(seed, setenv, ctx):
     rng = np.random.default_rng(91000 + seed)
     kind = ["ls", "ls", "sqrt", "wls"][seed % 4]
     tall = bool(rng.integers(0, 2))                    # tall: the gradient cache's guard (n >= 32 nnz) lets its passes run
@@ -73,11 +92,11 @@ def test_random_call_sequences_on_one_handle(seed, monkeypatch):
         n = max(n, 2 * p)                              # (the sqrt-lasso needs lambda^2 < ||X_k||^2: comfortably over-determined)
     s = int(rng.integers(1, min(10, p) + 1))
     # env knobs are read when the handle is created
-    monkeypatch.setenv("CDH_SMALL_PATH", str(int(rng.integers(0, 2))))
+    setenv("CDH_SMALL_PATH", str(int(rng.integers(0, 2))))
     if rng.integers(0, 3) == 0:
-        monkeypatch.setenv("CDH_GC_REFRESH", str(int(rng.integers(20, 400))))      # re-references of the cached gradient mid-solve
+        setenv("CDH_GC_REFRESH", str(int(rng.integers(20, 400))))      # re-references of the cached gradient mid-solve
     if rng.integers(0, 3) == 0:
-        monkeypatch.setenv("CDH_GC_INJECT_ROLLBACK", str(int(rng.integers(1, 4))))  # device-side cache passes undone
+        setenv("CDH_GC_INJECT_ROLLBACK", str(int(rng.integers(1, 4))))  # device-side cache passes undone
     X = np.asfortranarray(rng.standard_normal((n, p)) * rng.uniform(0.4, 2.5, size=p))
     Y = X[:, :s] @ rng.standard_normal(s) + rng.uniform(0.3, 2.0) * rng.standard_normal(n)
     w = rng.uniform(0.5, 1.5, size=n) if kind == "wls" else None
@@ -90,7 +109,11 @@ def test_random_call_sequences_on_one_handle(seed, monkeypatch):
             return O.CDWeightedLSLoss(Y, X, w)
         return O.CDLeastSquaresLoss(Y, X)
 
-    f = {"ls": cd.CDLeastSquaresLoss, "sqrt": cd.CDSqrtLassoLoss}[kind](Y, X) if kind != "wls" else cd.CDWeightedLSLoss(Y, X, w)
+    rows = ctx.rows(n)
+    if kind == "wls":
+        f = ctx.make(cd.CDWeightedLSLoss, n, Y[rows], X[rows], w[rows])
+    else:
+        f = ctx.make({"ls": cd.CDLeastSquaresLoss, "sqrt": cd.CDSqrtLassoLoss}[kind], n, Y[rows], X[rows])
     fo = oracle_loss()
     f.set_gradient_cache(int(rng.choice([0, 1, 2, 3, 3])))
     f.set_sweep_mode(["coord", "block"][int(rng.integers(0, 2))], int(rng.choice([2, 8, 16, 32, 64])))
@@ -115,6 +138,7 @@ def test_random_call_sequences_on_one_handle(seed, monkeypatch):
             st = O.coordinateDescent_(xo, fo, O.ProxL1(lam, om), O.CDOptions(**o))
             cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(**o))
             REACHED["solves"] = REACHED.get("solves", 0) + 1
+            ctx.check_replicas(x, log)
             assert f.last_stats["converged"] == st["converged"], " | ".join(log)
             _check_iterates(x, xo, log, strict_order=False)
             assert sorted(x.nzval2ind.tolist()) == sorted(xo.nzval2ind.tolist()), "\n".join(log)
@@ -160,14 +184,14 @@ def test_random_call_sequences_on_one_handle(seed, monkeypatch):
             k = int(rng.integers(1, p + 1))
             log.append(f"gradient k={k}, lambda_max, residual")
             np.testing.assert_allclose(cd.gradient(f, x, k), O.gradient(fo, xo, k), rtol=1e-8, atol=1e-11, err_msg=" | ".join(log))
-            np.testing.assert_allclose(f.r, Y - X @ x.dense(), rtol=0, atol=1e-9 * max(1.0, float(np.max(np.abs(Y)))),
+            np.testing.assert_allclose(f.r, (Y - X @ x.dense())[rows], rtol=0, atol=1e-9 * max(1.0, float(np.max(np.abs(Y)))),
                                        err_msg=" | ".join(log))
         elif op == 8:                                  # new penalty weights (or none)
             om = rng.uniform(0.5, 2.0, size=p) if rng.integers(0, 3) else None
             log.append("new omega" if om is not None else "omega dropped")
         elif op == 9:                                  # a new y on the same X: the same handle, a fresh oracle loss
             Y = X[:, :s] @ rng.standard_normal(s) + rng.uniform(0.3, 2.0) * rng.standard_normal(n)
-            yc = np.ascontiguousarray(Y)
+            yc = np.ascontiguousarray(Y[rows])
             cd._lib.check(f._L.cdh_set_y(f._h, yc.ctypes.data), f._h)
             fo = oracle_loss()
             cd.initialize_(f, x)                       # r = y - X beta for the iterate carried over
@@ -177,8 +201,8 @@ def test_random_call_sequences_on_one_handle(seed, monkeypatch):
             j0 = int(rng.integers(0, p))
             nc = int(rng.integers(1, min(p - j0, 12) + 1))
             X[:, j0:j0 + nc] = rng.standard_normal((n, nc)) * rng.uniform(0.4, 2.5, size=nc)
-            blk = np.asfortranarray(X[:, j0:j0 + nc])
-            cd._lib.check(f._L.cdh_set_X_cols(f._h, j0, nc, blk.ctypes.data, n), f._h)
+            blk = np.asfortranarray(X[rows, j0:j0 + nc])
+            cd._lib.check(f._L.cdh_set_X_cols(f._h, j0, nc, blk.ctypes.data, blk.shape[0]), f._h)
             fo = oracle_loss()
             cd.initialize_(f, x)
             O.initialize_(fo, xo)
@@ -210,7 +234,7 @@ def test_random_call_sequences_on_one_handle(seed, monkeypatch):
         else:                                          # new observation weights (weighted loss), else a path switch
             if kind == "wls":
                 w = rng.uniform(0.5, 1.5, size=n)
-                wc = np.ascontiguousarray(w)
+                wc = np.ascontiguousarray(w[rows])
                 cd._lib.check(f._L.cdh_set_obs_weights(f._h, wc.ctypes.data), f._h)
                 fo = oracle_loss()
                 cd.initialize_(f, x)
@@ -285,6 +309,27 @@ def test_random_call_sequences_on_one_fp32_handle(seed, monkeypatch):
     for k, v in dict(f.cache_stats(), onchip_solves=f.onchip_stats()["solves"]).items():
         REACHED["fp32_" + k] = REACHED.get("fp32_" + k, 0) + int(v)
     f.close()
+
+
+def test_random_call_sequences_on_row_shards():
+    """The same sequences with the loss object a ROW SHARD on each of two ranks (one GPU, host-staged exchange behind the
+    library's all-reduce seam: tests/stateful_fuzz_worker.py): the sharded launch sequences, the cache's Gram batches and
+    device-side passes over shards, and the state they carry, under the same switches."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    count = max(12, N_SEQ // 2)
+    a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "tests", "stateful_fuzz_worker.py"), "0", str(count)],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert a.returncode == 0, (a.stdout[-1500:], a.stderr[-4000:])
+    assert f"FUZZ_SHARDS_OK {count}" in a.stdout
 
 
 def test_the_sequences_reached_the_paths_that_carry_state():
