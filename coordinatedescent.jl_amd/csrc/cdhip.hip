@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -141,7 +142,9 @@ struct GradCache {
 // control block of the solve kernel, pinned staging for what comes back.
 constexpr int kSmallMaxP = 1024;
 constexpr int kSmallMaxLam = 64;                 // solves per launch (a cold start's numSteps + 1 = 51 by default)
-constexpr size_t kSmallMaxBytes = (size_t)16 << 20;
+// How much X the Gram form is worth building for is a cost comparison (small_worth_building, small_solve.hpp); X that fits
+// kSmallAlwaysBytes takes it regardless (the reference's own test and benchmark shapes).
+constexpr size_t kSmallAlwaysBytes = (size_t)16 << 20;
 
 struct SmallCtl {
     double lambdas[kSmallMaxLam];
@@ -161,6 +164,9 @@ struct SmallCtl {
 
 struct SmallPath {
     bool enabled = true;             // env CDH_SMALL_PATH (default 1), cdh_set_small_path
+    int64_t max_bytes = -1;          // env CDH_SMALL_MAX_BYTES: a fixed limit on n p sz instead of rent-or-buy (experiments)
+    double rent_paid = 0.0;          // seconds of streamed solves on the current X while G was not built (small_applicable)
+    int64_t* d_iota = nullptr;       // 0 .. p-1: the column lists of the Gram build
     bool G_valid = false;
     double* d_G = nullptr;           // p x p
     char *d_io = nullptr, *h_io = nullptr;    // [SmallCtl][support][beta]: what crosses the bus per solve, one block each way
@@ -1018,6 +1024,7 @@ void free_all(cdh_handle h) {
     if (h->gc.d_slot) (void)hipFree(h->gc.d_slot);
     if (h->gc.h_g_pin) (void)hipHostFree(h->gc.h_g_pin);
     if (h->small.d_G) (void)hipFree(h->small.d_G);
+    if (h->small.d_iota) (void)hipFree(h->small.d_iota);
     if (h->small.d_io) (void)hipFree(h->small.d_io);
     if (h->small.d_ca) (void)hipFree(h->small.d_ca);
     if (h->small.h_io) (void)hipHostFree(h->small.h_io);
@@ -1103,6 +1110,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->gc.mode = std::max(0, std::min(3, env_int("CDH_GRADIENT_CACHE", 1)));
         h->gc.cov = env_int("CDH_GC_COV", 1) != 0;
         h->small.enabled = env_int("CDH_SMALL_PATH", 1) != 0;
+        if (const char* e = getenv("CDH_SMALL_MAX_BYTES")) h->small.max_bytes = std::atoll(e);
         h->gc.inject_rollback = std::max(0, env_int("CDH_GC_INJECT_ROLLBACK", 0));
         h->gc.refresh_after = std::max(1, env_int("CDH_GC_REFRESH", (int)kGcCovRefresh));
         const int step_per_cu = std::max(1, env_int("CDH_STEP_GRID_PER_CU", 8));
@@ -1188,7 +1196,7 @@ int32_t cdh_set_X_cols(cdh_handle h, int64_t j0, int64_t ncols, const void* host
     }
     h->r_consistent = false;
     gc_invalidate(h, true);
-    h->small.G_valid = false; h->small.c_valid = false;
+    h->small.G_valid = false; h->small.c_valid = false; h->small.rent_paid = 0.0;
     if (j0 < 0 || ncols < 0 || j0 + ncols > h->p || ld < h->n) return fail(h, CDH_DIM_MISMATCH, "column block outside X");
     if (ncols == 0) return CDH_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1251,7 +1259,7 @@ int32_t cdh_set_obs_weights(cdh_handle h, const void* host_w) {
     NEED_P(h, host_w);
     h->r_consistent = false;
     gc_invalidate(h, true);
-    h->small.G_valid = false; h->small.c_valid = false;
+    h->small.G_valid = false; h->small.c_valid = false; h->small.rent_paid = 0.0;
     if (h->loss != CDH_WLS) return fail(h, CDH_BAD_ARG, "observation weights need the CDH_WLS loss");
     HIPCHK(h, hipSetDevice(h->device));
     CHK(ensure_weights_buffer(h));
@@ -1269,7 +1277,7 @@ int32_t cdh_set_loss(cdh_handle h, int32_t loss) {
     if (loss == CDH_WLS) CHK(ensure_weights_buffer(h));
     h->loss = loss;
     h->ctrl.loss = loss;          // goes to the device with the next chunk's control block
-    if (h->has_w) { h->small.G_valid = false; h->small.c_valid = false; gc_invalidate(h, true); }   // X'WX is not X'X
+    if (h->has_w) { h->small.G_valid = false; h->small.c_valid = false; h->small.rent_paid = 0.0; gc_invalidate(h, true); }   // X'WX is not X'X
     h->has_w = false;             // a weighted loss gets its weights from cdh_set_obs_weights
     h->r_consistent = false;
     gc_invalidate(h, false);
@@ -1281,7 +1289,7 @@ static int32_t cdh_generate_impl(cdh_handle h, uint64_t seed, int64_t s, double 
     if (s < 0 || s > h->p) return fail(h, CDH_BAD_ARG, "need 0 <= s <= p");
     gc_invalidate(h, true);
     h->gc.yy_ok = false;
-    h->small.G_valid = false; h->small.c_valid = false;
+    h->small.G_valid = false; h->small.c_valid = false; h->small.rent_paid = 0.0;
     drop_r_pending(h);
     h->r_lazy = false;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1451,6 +1459,7 @@ static int32_t cdh_solve_impl(cdh_handle h, const cdh_options* opt, cdh_stats* o
         }
     }
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
+    SmallRent rent(h, opt);
     int32_t rc = solve(h, opt, sched, &st);
     if (out) *out = st;
     return rc;
@@ -1463,8 +1472,9 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
     h->domain_error = false;
     int32_t rc = CDH_OK;
-    bool small = small_applicable(h, opt);
+    bool small = small_applicable(h, opt, !opt->warmStart);   // a cold start is numSteps + 1 solves: it buys the Gram form outright
     if (small) { CHK(small_prepare(h)); small = h->small.enabled; }
+    SmallRent rent(h, opt);
     uint64_t rng = opt->seed;       // the one-launch solve carries the scheduler's generator state itself
     if (opt->warmStart && small) {
         // initialize!(f, x) (:21) makes r = y - X x by definition: the one-launch solve derives its gradient from that

@@ -336,11 +336,45 @@ inline size_t small_sup_off() { return (sizeof(SmallCtl) + 15) / 16 * 16; }
 inline size_t small_beta_off(int64_t p) { return small_sup_off() + ((size_t)p * sizeof(int32_t) + 15) / 16 * 16; }
 inline size_t small_io_bytes(int64_t p) { return small_beta_off(p) + (size_t)p * sizeof(double); }
 
-inline bool small_applicable(const cdh_handle_s* h, const cdh_options* o) {
-    return h->small.enabled && !sharded(h) && h->p <= kSmallMaxP && (size_t)h->ld * (size_t)h->p * h->esz <= kSmallMaxBytes &&
+// Is the full Gram matrix worth building for this X?  X that fits kSmallAlwaysBytes: always (the build is a fraction of
+// a millisecond: the reference's own shapes).  Beyond that it is rent or buy.  A solve on the streamed kernels is cheap where
+// its passes are served by the screens and the gradient cache (measured, tools/midsize_solve.py: ~1 ms at 80 .. 400 MB of X,
+// 3 ms at 3 GB), and building G costs ceil(p / 32) passes over X (1.5 .. 7 ms there) -- more than ONE such solve, a tenth of
+// the 51 solves of a cold start, and every later solve then takes 0.1 .. 0.2 ms instead of 1 .. 10.  So the handle pays rent
+// -- runs its solves streamed, timing them -- until the rent paid on this X reaches the price of the build; a cold start
+// (numSteps + 1 solves at once) buys a cheap build outright.  Never worse than about twice the better choice, whatever the
+// caller does next.
+inline double small_build_estimate(const cdh_handle_s* h) {
+    const double bytes = (double)h->ld * (double)h->p * (double)h->esz;
+    return (double)((h->p + 31) / 32 + 1) * std::max(bytes / 4.0e12, 40e-6);
+}
+inline bool small_candidate(const cdh_handle_s* h, const cdh_options* o) {      // everything but the rent-or-buy decision
+    return h->small.enabled && !sharded(h) && h->p <= kSmallMaxP &&
            h->gc.mode != 3 /* tests force the gradient cache's own path with mode 3 */ && (h->loss != CDH_WLS || h->has_w) &&
            o->numSteps + 1 <= kSmallMaxLam && o->numSteps >= 1;
 }
+inline bool small_applicable(const cdh_handle_s* h, const cdh_options* o, bool many_solves = false) {
+    if (!small_candidate(h, o)) return false;
+    const double bytes = (double)h->ld * (double)h->p * (double)h->esz;
+    if (h->small.max_bytes >= 0) return bytes <= (double)h->small.max_bytes;
+    if (h->small.G_valid || bytes <= (double)kSmallAlwaysBytes) return true;
+    const double price = small_build_estimate(h);
+    // (a cold start on the streamed kernels takes ~10 ms at any of these sizes -- the gradient cache serves most of its
+    // passes -- so it buys outright only a build well under that)
+    return (many_solves && price <= 3e-3) || h->small.rent_paid >= price;
+}
+// a streamed solve on a handle that could have had the Gram form: its wall time is rent paid on this X
+struct SmallRent {
+    cdh_handle_s* h;
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    SmallRent(cdh_handle_s* h_, const cdh_options* o) : h(h_), on(small_candidate(h_, o) && !h_->small.G_valid) {
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    ~SmallRent() {
+        if (on) h->small.rent_paid += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
 // (Measured and dropped, round 3: the same state machine in RESIDUAL form for short columns and many coordinates -- the
 // reference's benchmark itself is n = 3000, p = 5000, where no Gram matrix fits -- as ONE workgroup with the residual in
 // registers and the next columns prefetched into a ring of registers.  Correct (47 parity cases), but every column has to come
@@ -393,19 +427,24 @@ int32_t small_prepare(cdh_handle h) {     // buffers, X'y and diag(G) of the cur
     }
     if (sp.G_valid) return CDH_OK;
     const int64_t launches = (h->p + kCrossA - 1) / kCrossA;
-    std::vector<int64_t> cols((size_t)kCrossB);
+    if (!sp.d_iota) {                 // the column lists of all batches, uploaded once: the batches then run back to back
+        std::vector<int64_t> iota((size_t)h->p);
+        for (int64_t k = 0; k < h->p; ++k) iota[(size_t)k] = k;
+        if (hipMalloc((void**)&sp.d_iota, sizeof(int64_t) * (size_t)h->p) != hipSuccess) { (void)hipGetLastError(); sp.enabled = false; return CDH_OK; }
+        HIPCHK(h, hipMemcpyAsync(sp.d_iota, iota.data(), sizeof(int64_t) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     for (int64_t b0 = 0; b0 < h->p; b0 += kCrossB) {
         const int nbc = (int)std::min<int64_t>(kCrossB, h->p - b0);
-        for (int b = 0; b < nbc; ++b) cols[(size_t)b] = b0 + b;
-        HIPCHK(h, hipMemcpyAsync(c.d_cols, cols.data(), sizeof(int64_t) * (size_t)nbc, hipMemcpyHostToDevice, h->stream));
+        const int64_t* cols = sp.d_iota + b0;
         CHK(dispatch(h, [&](auto* t) {
             using T = std::remove_pointer_t<decltype(t)>;
             const dim3 grid((unsigned)c.cross_GX, (unsigned)c.cross_J), block(64 * kGramWaves);
             if (h->has_w)
-                hipLaunchKernelGGL((k_cross<T, true>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc,
+                hipLaunchKernelGGL((k_cross<T, true>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, cols, nbc,
                                    (const T*)h->w, c.d_cross_part);
             else
-                hipLaunchKernelGGL((k_cross<T, false>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc,
+                hipLaunchKernelGGL((k_cross<T, false>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, cols, nbc,
                                    (const T*)nullptr, c.d_cross_part);
             return CDH_OK;
         }));
@@ -414,7 +453,6 @@ int32_t small_prepare(cdh_handle h) {     // buffers, X'y and diag(G) of the cur
         hipLaunchKernelGGL(k_small_unpack, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_cross, h->p, (int)b0, nbc,
                            sp.d_G);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipStreamSynchronize(h->stream));     // `cols` is reused by the next batch
     }
     sp.G_valid = true;
     sp.n_gram += 1;

@@ -126,7 +126,7 @@ def connect_checked(loss, cp: ControlPlane, unique_id=None) -> tuple[bool, str]:
     standing in for cdh_comm_unique_id on rank 0."""
     import numpy as np
     from . import _lib
-    if cp.world == 1:
+    if cp.world == 1 and not os.environ.get("CDH_FORCE_RCCL"):     # (forced: a 1-rank communicator, as connect())
         return True, ""
 
     def agree(ok: bool, why: str) -> tuple[bool, str]:

@@ -227,8 +227,10 @@ int32_t cdh_cache_stats(cdh_handle h, int64_t *out10);
  * -- the quantity the certificates' relative margin (1e-9 for fp64 storage) has to cover.
  * out3 = {drift at the last re-reference, the largest seen on this handle, re-references measured}. */
 int32_t cdh_cache_drift(cdh_handle h, int32_t rereference_now, double *out3);
-/* Problems that fit on chip -- p <= 1024 and n p sizeof(T) <= 16 MB, one process: the reference's own test and
- * benchmark shapes (test/lasso.jl:76-101, benchmark/cd_bench.jl:8-14) -- are solved in ONE launch: the handle keeps the
+/* Problems whose Gram matrix fits on chip -- p <= 1024 columns, one process -- are solved in ONE launch.  With at most
+ * 16 MB of X (the reference's own test and benchmark shapes: test/lasso.jl:76-101, benchmark/cd_bench.jl:8-14) from the
+ * first solve; with more, once the solves the handle ran on the streamed kernels have cost what building the matrix
+ * would (ceil(p / 32) passes over X; a cold start, being numSteps + 1 solves, buys a cheap build outright).  The handle keeps the
  * full Gram matrix X'X (X'WX) of the resident X, and one wave runs the whole of _coordinateDescent!
  * (coordinate_descent.jl:65-92; a cold start's numSteps + 1 solves, :32-36, in the same launch) in covariance form, with
  * the SparseIterate bookkeeping that fixes the visit order of active passes replayed on the device.  Same iterates as the

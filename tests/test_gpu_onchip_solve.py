@@ -230,7 +230,8 @@ def test_new_columns_new_y_and_the_size_limits():
     np.testing.assert_allclose(x.dense(), O.lasso(Xn, Y2, 0.08, None, O.CDOptions(**o)).x.dense(), rtol=0, atol=BETA_TOL)
     assert f.onchip_stats() == {"solves": 3, "gram_matrices": 2}
     f.close()
-    # beyond the limits (p > 1024, or more than 16 MB of X) every solve stays on the streamed kernels
+    # beyond the limits (p > 1024; more than 16 MB of X: until the streamed solves have cost what building G would) a solve
+    # stays on the streamed kernels
     for n, p in ((300, 1100), (9000, 300)):
         rng, X, Y = _problem(75, n, p, 5)
         f = cd.CDLeastSquaresLoss(Y, X)
@@ -239,6 +240,36 @@ def test_new_columns_new_y_and_the_size_limits():
         assert f.onchip_stats() == {"solves": 0, "gram_matrices": 0}
         np.testing.assert_allclose(x.dense(), O.lasso(X, Y, 0.2, None, O.CDOptions(**o)).x.dense(), rtol=0, atol=BETA_TOL)
         f.close()
+
+
+def test_rent_or_buy_beyond_the_always_limit():
+    """More than 16 MB of X: the Gram matrix is built once the solves run on the streamed kernels have cost as much as
+    building it would (small_applicable, csrc/small_solve.hpp) -- here within a few solves -- and a cold start, being
+    numSteps + 1 solves at once, buys a cheap build outright.  Same iterates as the oracle on either side of the switch."""
+    rng, X, Y = _problem(77, 9000, 300, 8)                                         # 21.6 MB
+    o = dict(maxIter=5000, optTol=1e-12, randomize=False)
+    f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+    x, xo = cd.SparseIterate(300), O.SparseIterate(300)
+    seen = []
+    for lam in (0.30, 0.24, 0.19, 0.15, 0.12, 0.09, 0.07, 0.05):
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"]
+        seen.append(f.onchip_stats()["solves"])
+    assert seen[0] == 0                                   # the first solve pays rent
+    assert seen[-1] > 0 and f.onchip_stats()["gram_matrices"] == 1
+    first = next(i for i, v in enumerate(seen) if v > 0)
+    assert seen[first:] == list(range(1, len(seen) - first + 1))      # once built, every solve is one launch
+    np.testing.assert_allclose(f.r, Y - X @ x.dense(), rtol=0, atol=1e-9)
+    f.close()
+    f = cd.CDLeastSquaresLoss(Y, X)                        # a cold start on a new handle: 51 solves, one launch
+    x, xo = cd.SparseIterate(300), O.SparseIterate(300)
+    cd.coordinateDescent_(x, f, cd.ProxL1(0.05), cd.CDOptions(warmStart=False, **o))
+    O.coordinateDescent_(xo, fo, O.ProxL1(0.05), O.CDOptions(warmStart=False, **o))
+    np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+    assert f.onchip_stats() == {"solves": 51, "gram_matrices": 1}
+    f.close()
 
 
 def test_zero_column_fp32_storage_and_maxiter():
