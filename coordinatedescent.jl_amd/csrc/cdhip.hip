@@ -165,6 +165,7 @@ struct SmallCtl {
 struct SmallPath {
     bool enabled = true;             // env CDH_SMALL_PATH (default 1), cdh_set_small_path
     int64_t max_bytes = -1;          // env CDH_SMALL_MAX_BYTES: a fixed limit on n p sz instead of rent-or-buy (experiments)
+    int64_t always_bytes = (int64_t)kSmallAlwaysBytes;   // env CDH_SMALL_ALWAYS_BYTES (tests: 0 makes every handle rent first)
     double rent_paid = 0.0;          // seconds of streamed solves on the current X while G was not built (small_applicable)
     int64_t* d_iota = nullptr;       // 0 .. p-1: the column lists of the Gram build
     bool G_valid = false;
@@ -1111,6 +1112,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->gc.cov = env_int("CDH_GC_COV", 1) != 0;
         h->small.enabled = env_int("CDH_SMALL_PATH", 1) != 0;
         if (const char* e = getenv("CDH_SMALL_MAX_BYTES")) h->small.max_bytes = std::atoll(e);
+        if (const char* e = getenv("CDH_SMALL_ALWAYS_BYTES")) h->small.always_bytes = std::atoll(e);
         h->gc.inject_rollback = std::max(0, env_int("CDH_GC_INJECT_ROLLBACK", 0));
         h->gc.refresh_after = std::max(1, env_int("CDH_GC_REFRESH", (int)kGcCovRefresh));
         const int step_per_cu = std::max(1, env_int("CDH_STEP_GRID_PER_CU", 8));

@@ -357,7 +357,7 @@ inline bool small_applicable(const cdh_handle_s* h, const cdh_options* o, bool m
     if (!small_candidate(h, o)) return false;
     const double bytes = (double)h->ld * (double)h->p * (double)h->esz;
     if (h->small.max_bytes >= 0) return bytes <= (double)h->small.max_bytes;
-    if (h->small.G_valid || bytes <= (double)kSmallAlwaysBytes) return true;
+    if (h->small.G_valid || bytes <= (double)h->small.always_bytes) return true;
     const double price = small_build_estimate(h);
     // (a cold start on the streamed kernels takes ~10 ms at any of these sizes -- the gradient cache serves most of its
     // passes -- so it buys outright only a build well under that)

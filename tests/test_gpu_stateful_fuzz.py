@@ -97,10 +97,11 @@ def run_sequence(seed, setenv, ctx):
         setenv("CDH_GC_REFRESH", str(int(rng.integers(20, 400))))      # re-references of the cached gradient mid-solve
     if rng.integers(0, 3) == 0:
         setenv("CDH_GC_INJECT_ROLLBACK", str(int(rng.integers(1, 4))))  # device-side cache passes undone
+    setenv("CDH_SMALL_ALWAYS_BYTES", ["16777216", "16777216", "0"][int(rng.integers(0, 3))])   # 0: the handle rents before it builds G
     X = np.asfortranarray(rng.standard_normal((n, p)) * rng.uniform(0.4, 2.5, size=p))
     Y = X[:, :s] @ rng.standard_normal(s) + rng.uniform(0.3, 2.0) * rng.standard_normal(n)
     w = rng.uniform(0.5, 1.5, size=n) if kind == "wls" else None
-    log = [f"seed={seed} kind={kind} n={n} p={p} env={ {k: os.environ.get(k) for k in ('CDH_SMALL_PATH', 'CDH_GC_REFRESH', 'CDH_GC_INJECT_ROLLBACK')} }"]
+    log = [f"seed={seed} kind={kind} n={n} p={p} env={ {k: os.environ.get(k) for k in ('CDH_SMALL_PATH', 'CDH_SMALL_ALWAYS_BYTES', 'CDH_GC_REFRESH', 'CDH_GC_INJECT_ROLLBACK')} }"]
 
     def oracle_loss():
         if kind == "sqrt":
