@@ -391,5 +391,14 @@ set_use_graph!(X::HipMatrix, on::Bool) =
   check(X.handle, ccall((:cdh_set_use_graph, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, on ? 1 : 0))
 set_reuse_residual!(X::HipMatrix, on::Bool) =
   check(X.handle, ccall((:cdh_set_reuse_residual, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, on ? 1 : 0))
+"The one-launch solve of problems whose Gram matrix fits on chip (p ≤ 1024; on by default): the reference's own shapes"
+set_onchip_solve!(X::HipMatrix, on::Bool) =
+  check(X.handle, ccall((:cdh_set_onchip_solve, libcdhip), Int32, (Ptr{Cvoid}, Int32), X.handle, on ? 1 : 0))
+"(solves run in one launch, Gram matrices built) on this design so far"
+function onchip_stats(X::HipMatrix)
+  out = zeros(Int64, 2)
+  check(X.handle, ccall((:cdh_onchip_stats, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Int64}), X.handle, out))
+  (out[1], out[2])
+end
 
 end # module
