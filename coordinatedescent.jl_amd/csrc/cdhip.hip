@@ -10,7 +10,6 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -166,7 +165,7 @@ struct SmallPath {
     bool enabled = true;             // env CDH_SMALL_PATH (default 1), cdh_set_small_path
     int64_t max_bytes = -1;          // env CDH_SMALL_MAX_BYTES: a fixed limit on n p sz instead of rent-or-buy (experiments)
     int64_t always_bytes = (int64_t)kSmallAlwaysBytes;   // env CDH_SMALL_ALWAYS_BYTES (tests: 0 makes every handle rent first)
-    double rent_paid = 0.0;          // seconds of streamed solves on the current X while G was not built (small_applicable)
+    double rent_paid = 0.0;          // modelled seconds of streamed solves on the current X while G was not built (SmallRent)
     int64_t* d_iota = nullptr;       // 0 .. p-1: the column lists of the Gram build
     bool G_valid = false;
     double* d_G = nullptr;           // p x p
@@ -1461,8 +1460,9 @@ static int32_t cdh_solve_impl(cdh_handle h, const cdh_options* opt, cdh_stats* o
         }
     }
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
-    SmallRent rent(h, opt);
+    const SmallRent rent(h, opt);
     int32_t rc = solve(h, opt, sched, &st);
+    rent.pay(st);
     if (out) *out = st;
     return rc;
 }
@@ -1476,7 +1476,7 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
     int32_t rc = CDH_OK;
     bool small = small_applicable(h, opt, !opt->warmStart);   // a cold start is numSteps + 1 solves: it buys the Gram form outright
     if (small) { CHK(small_prepare(h)); small = h->small.enabled; }
-    SmallRent rent(h, opt);
+    const SmallRent rent(h, opt);
     uint64_t rng = opt->seed;       // the one-launch solve carries the scheduler's generator state itself
     if (opt->warmStart && small) {
         // initialize!(f, x) (:21) makes r = y - X x by definition: the one-launch solve derives its gradient from that
@@ -1535,6 +1535,7 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
             HIPCHK(h, hipStreamSynchronize(h->stream));
         }
     }
+    if (!small) rent.pay(st);
     if (out) *out = st;
     return rc;
 }

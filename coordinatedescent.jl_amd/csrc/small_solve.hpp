@@ -341,7 +341,7 @@ inline size_t small_io_bytes(int64_t p) { return small_beta_off(p) + (size_t)p *
 // its passes are served by the screens and the gradient cache (measured, tools/midsize_solve.py: ~1 ms at 80 .. 400 MB of X,
 // 3 ms at 3 GB), and building G costs ceil(p / 32) passes over X (1.5 .. 7 ms there) -- more than ONE such solve, a tenth of
 // the 51 solves of a cold start, and every later solve then takes 0.1 .. 0.2 ms instead of 1 .. 10.  So the handle pays rent
-// -- runs its solves streamed, timing them -- until the rent paid on this X reaches the price of the build; a cold start
+// -- runs its solves streamed, pricing their passes -- until the rent paid on this X reaches the price of the build; a cold start
 // (numSteps + 1 solves at once) buys a cheap build outright.  Never worse than about twice the better choice, whatever the
 // caller does next.
 inline double small_build_estimate(const cdh_handle_s* h) {
@@ -363,16 +363,23 @@ inline bool small_applicable(const cdh_handle_s* h, const cdh_options* o, bool m
     // passes -- so it buys outright only a build well under that)
     return (many_solves && price <= 3e-3) || h->small.rent_paid >= price;
 }
-// a streamed solve on a handle that could have had the Gram form: its wall time is rent paid on this X
+// A streamed solve on a handle that could have had the Gram form pays rent on this X: what it did, priced by the model the
+// build's price comes from -- a host round trip per pass; a read of X per full pass the gradient cache did not serve and
+// per re-reference; a read and a half per batch of Gram columns -- rather than by the clock, so that WHICH solve of a
+// call sequence builds G (and with it the last bits of the iterates) does not depend on the machine's mood.
 struct SmallRent {
     cdh_handle_s* h;
     bool on;
-    std::chrono::steady_clock::time_point t0;
-    SmallRent(cdh_handle_s* h_, const cdh_options* o) : h(h_), on(small_candidate(h_, o) && !h_->small.G_valid) {
-        if (on) t0 = std::chrono::steady_clock::now();
-    }
-    ~SmallRent() {
-        if (on) h->small.rent_paid += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    int64_t cached0, refs0, batches0;
+    SmallRent(cdh_handle_s* h_, const cdh_options* o)
+        : h(h_), on(small_candidate(h_, o) && !h_->small.G_valid), cached0(h_->gc.n_passes), refs0(h_->gc.n_validate),
+          batches0(h_->gc.n_batches) {}
+    void pay(const cdh_stats& st) const {
+        if (!on) return;
+        const double read = (double)h->ld * (double)h->p * (double)h->esz / 6.0e12;
+        const int64_t streamed_full = std::max<int64_t>(0, st.full_passes - (h->gc.n_passes - cached0));
+        h->small.rent_paid += 40e-6 * (double)st.passes +
+                              read * ((double)streamed_full + (double)(h->gc.n_validate - refs0) + 1.5 * (double)(h->gc.n_batches - batches0));
     }
 };
 // (Measured and dropped, round 3: the same state machine in RESIDUAL form for short columns and many coordinates -- the
