@@ -329,6 +329,14 @@ inline bool sharded(const cdh_handle_s* h) {
     return h->comm != nullptr || h->p2p_on || h->p2p_dead || h->lost_exchange || h->host_fn != nullptr;
 }
 
+// A shard that has lost its exchange refuses to sweep at all -- also where a pass could be served from sums exchanged
+// earlier (the gradient cache): the ranks of one problem must fail together, not one by one as they come to need an exchange.
+int32_t exchange_alive(cdh_handle h) {
+    if (h->p2p_dead) return fail(h, CDH_RCCL_ERROR, "the shard lost its exchange (p2p timed out earlier); rebuild the handle");
+    if (h->lost_exchange) return fail(h, CDH_RCCL_ERROR, "the shard's host exchange was removed and nothing replaced it: its sums would cover local rows only");
+    return CDH_OK;
+}
+
 int32_t p2p_check(cdh_handle h) {
     // after a timeout the ranks no longer agree on what has been exchanged: the handle refuses every
     // later exchange (falling back to RCCL here could pair mismatched all-reduces and hang)
@@ -390,8 +398,7 @@ int32_t allreduce(cdh_handle h, double* dbuf, size_t count) {
         HIPCHK(h, hipGetLastError());
         return CDH_OK;
     }
-    if (h->p2p_dead) return fail(h, CDH_RCCL_ERROR, "the shard lost its exchange (p2p timed out earlier); rebuild the handle");
-    if (h->lost_exchange) return fail(h, CDH_RCCL_ERROR, "the shard's host exchange was removed and nothing replaced it: its sums would cover local rows only");
+    CHK(exchange_alive(h));
     if (!h->comm) return CDH_OK;
     int rc = g_rccl.AllReduce(dbuf, dbuf, count, kNcclDouble, kNcclSum, h->comm, h->stream);
     if (rc != 0) {
@@ -885,7 +892,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
 // repeated hits), so a pass in which everything moves pays for a handful of screens only; a screen
 // that settles all of its columns doubles the next one (64 -> 1024 columns: one host round trip per
 // screen, so long quiet stretches run at the plain streaming rate of k_col_dots).
-constexpr int kScreen = 64, kScreenMax = 1024;
+constexpr int kScreen = 64, kScreenMax = 1024, kScreenMinPass = 16;   // (passes over fewer coordinates than that: a block or two anyway)
 
 int32_t screened_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH) {
     {   // from the gradient cache when it is engaged: no read of X for the settled visits at all
@@ -952,7 +959,7 @@ int32_t screened_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double*
 // _cdPass! (coordinate_descent.jl:94-110)
 int32_t run_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, bool screen = false) {
     *maxH = 0.0;
-    if (screen && h->screening && (h->loss != CDH_WLS || h->has_w) && m >= 2 * kScreen && h->x.nnz() * 4 <= h->p) {
+    if (screen && h->screening && (h->loss != CDH_WLS || h->has_w) && m >= kScreenMinPass && h->x.nnz() * 4 <= h->p) {
         CHK(screened_full_pass(h, idx0, m, maxH));
     } else {
         for (int64_t off = 0; off < m; off += h->cap) {
@@ -1431,6 +1438,7 @@ static int32_t cdh_lambda_max_impl(cdh_handle h, double* out) {
 
 static int32_t cdh_pass_impl(cdh_handle h, int64_t m, const int64_t* idx1, double* out_maxH) {
     if (m < 0) return fail(h, CDH_BAD_ARG, "m < 0");
+    CHK(exchange_alive(h));
     if (m > 0) NEED_P(h, idx1);
     HIPCHK(h, hipSetDevice(h->device));
     std::vector<int64_t> idx0((size_t)m);
@@ -1447,6 +1455,7 @@ static int32_t cdh_pass_impl(cdh_handle h, int64_t m, const int64_t* idx1, doubl
 
 static int32_t cdh_solve_impl(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
     NEED_P(h, opt);
+    CHK(exchange_alive(h));
     HIPCHK(h, hipSetDevice(h->device));
     cdh_stats st{};
     if (small_applicable(h, opt)) {
@@ -1469,6 +1478,7 @@ static int32_t cdh_solve_impl(cdh_handle h, const cdh_options* opt, cdh_stats* o
 
 static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt, cdh_stats* out) {
     NEED_P(h, opt);
+    CHK(exchange_alive(h));
     HIPCHK(h, hipSetDevice(h->device));
     cdh_stats st{};
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
