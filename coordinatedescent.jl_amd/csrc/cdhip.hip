@@ -170,6 +170,8 @@ struct SmallPath {
     bool G_valid = false;
     double* d_G = nullptr;           // p x p
     char *d_io = nullptr, *h_io = nullptr;    // [SmallCtl][support][beta]: what crosses the bus per solve, one block each way
+    char* hd_io = nullptr;           // h_io as the device addresses it
+    bool zero_copy = true;           // env CDH_SMALL_ZEROCOPY (default 1): the kernel works on h_io itself, nothing is copied
     SmallCtl *d_ctl = nullptr, *h_ctl = nullptr;   // views into d_io / h_io (pinned)
     int32_t *d_sup = nullptr, *h_sup = nullptr;
     double *d_beta = nullptr, *h_beta = nullptr;
@@ -1118,6 +1120,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->gc.cov = env_int("CDH_GC_COV", 1) != 0;
         h->small.enabled = env_int("CDH_SMALL_PATH", 1) != 0;
         if (const char* e = getenv("CDH_SMALL_MAX_BYTES")) h->small.max_bytes = std::atoll(e);
+        h->small.zero_copy = env_int("CDH_SMALL_ZEROCOPY", 1) != 0;
         if (const char* e = getenv("CDH_SMALL_ALWAYS_BYTES")) h->small.always_bytes = std::atoll(e);
         h->gc.inject_rollback = std::max(0, env_int("CDH_GC_INJECT_ROLLBACK", 0));
         h->gc.refresh_after = std::max(1, env_int("CDH_GC_REFRESH", (int)kGcCovRefresh));

@@ -156,6 +156,11 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
     const int64_t maxIter = ctl->maxIter;
     uint64_t rng = ctl->rng;
     int nnz = ctl->nnz_in, ncached = 0;
+    const int g_from_c = ctl->g_from_c;
+    // (the control block may sit in pinned HOST memory -- small_solve: nothing is copied down or back then -- so it is read
+    // once, here: the lambdas of all the launch's solves in one wave load, handed out by v_readlane)
+    const double lam_lane = ctl->lambdas[lane];
+    static_assert(kSmallMaxLam == 64, "one lambda per lane");
     for (int k = lane; k < p; k += 64) {
         s_g[k] = ga[2 * k]; s_a[k] = ga[2 * k + 1]; s_beta[k] = beta[k];
         s_om[k] = has_omega ? omega[k] : 1.0;
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
     __syncthreads();
     for (int s = lane; s < nnz; s += 64) { const int k = sup[s]; s_slot2ind[s] = k; s_ind2slot[k] = s + 1; }
     double q = SQRT ? *q_in : 0.0;
-    if (ctl->g_from_c) {
+    if (g_from_c) {
         // `ga` held c = X'y (X'Wy), q_in y'y: the gradient and r'r of the iterate follow from the Gram matrix alone,
         //   g = c - G beta,   r'r = y'y - 2 beta'c + beta'G beta = y'y - sum_s beta_s (c_s + g_s)
         // -- no pass over X or r at all (a warm start from beta = 0 is g = c)
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
     double lastH = 0.0;
     __syncthreads();
     for (int il = 0; il < nlam; ++il) {
-        const double lambda0 = ctl->lambdas[il];
+        const double lambda0 = __shfl(lam_lane, il, 64);
         bool prev_conv = false, conv = true;
         converged = 0;
         for (int64_t iter = 0; iter < maxIter; ++iter) {
@@ -403,6 +408,9 @@ int32_t small_prepare(cdh_handle h) {     // buffers, X'y and diag(G) of the cur
                     hipHostMalloc((void**)&sp.h_io, small_io_bytes(h->p)) == hipSuccess;
         if (!fits) { (void)hipGetLastError(); sp.enabled = false; return CDH_OK; }
         sp.d_ctl = reinterpret_cast<SmallCtl*>(sp.d_io); sp.h_ctl = reinterpret_cast<SmallCtl*>(sp.h_io);
+        void* dev_view = nullptr;          // the pinned block as the device addresses it (zero-copy solves)
+        if (hipHostGetDevicePointer(&dev_view, sp.h_io, 0) == hipSuccess) sp.hd_io = static_cast<char*>(dev_view);
+        else (void)hipGetLastError();
         sp.d_sup = reinterpret_cast<int32_t*>(sp.d_io + small_sup_off()); sp.h_sup = reinterpret_cast<int32_t*>(sp.h_io + small_sup_off());
         sp.d_beta = reinterpret_cast<double*>(sp.d_io + small_beta_off(h->p)); sp.h_beta = reinterpret_cast<double*>(sp.h_io + small_beta_off(h->p));
         // dynamic LDS of the solve kernel: the p-sized state, then as many Gram columns as the rest of the CU's LDS holds
@@ -486,18 +494,25 @@ int32_t small_solve(cdh_handle h, const cdh_options* o, const double* lambdas, i
     ctl.maxIter = o->maxIter; ctl.optTol = o->optTol; ctl.n_total = (double)h->n_total; ctl.rng = *rng;
     ctl.nnz_in = (int32_t)h->x.nnz();
     for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) sp.h_sup[s_] = (int32_t)h->x.coord(s_);
-    // down: the control block and the support, one copy; back: those two and beta, one copy
-    HIPCHK(h, hipMemcpyAsync(sp.d_io, sp.h_io, small_sup_off() + sizeof(int32_t) * (size_t)h->x.nnz(), hipMemcpyHostToDevice, h->stream));
+    // What crosses the bus per solve is one block each way -- [control][support] down, [control][support][beta] back.
+    // Zero-copy (default): the kernel reads and writes that block in the pinned host buffer itself, a few hundred bytes
+    // each way over the bus inside the launch, instead of two copies queued around it (~10 us of a 90 us solve at cfg1).
+    const bool zc = sp.zero_copy && sp.hd_io != nullptr;
+    if (!zc)
+        HIPCHK(h, hipMemcpyAsync(sp.d_io, sp.h_io, small_sup_off() + sizeof(int32_t) * (size_t)h->x.nnz(), hipMemcpyHostToDevice, h->stream));
+    SmallCtl* k_ctl = zc ? reinterpret_cast<SmallCtl*>(sp.hd_io) : sp.d_ctl;
+    int32_t* k_sup = zc ? reinterpret_cast<int32_t*>(sp.hd_io + small_sup_off()) : sp.d_sup;
+    double* k_beta = zc ? reinterpret_cast<double*>(sp.hd_io + small_beta_off(h->p)) : sp.d_beta;
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(1), dim3(64), sp.lds_bytes, h->stream, sp.d_ctl, (int)h->p, sp.ncache, ga, sp.d_G,
-                           h->omega, qin, h->beta, sp.d_sup, sp.d_beta);
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(64), sp.lds_bytes, h->stream, k_ctl, (int)h->p, sp.ncache, ga, sp.d_G,
+                           h->omega, qin, h->beta, k_sup, k_beta);
     };
     const bool sq = h->loss == CDH_SQRT;
     if (h->p <= 256) { if (sq) go(k_solve_small<true, 4>); else go(k_solve_small<false, 4>); }
     else if (h->p <= 512) { if (sq) go(k_solve_small<true, 8>); else go(k_solve_small<false, 8>); }
     else { if (sq) go(k_solve_small<true, 16>); else go(k_solve_small<false, 16>); }
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(sp.h_io, sp.d_io, small_io_bytes(h->p), hipMemcpyDeviceToHost, h->stream));
+    if (!zc) HIPCHK(h, hipMemcpyAsync(sp.h_io, sp.d_io, small_io_bytes(h->p), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     // what moved becomes pending residual updates (r_actual = r_virtual + X * pending: sync_r applies them before anything
     // reads r) and, for a gradient cache that holds a reference, pending moves like those of any other visit
