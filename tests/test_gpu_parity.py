@@ -1197,6 +1197,7 @@ def test_gradient_cache_default_mode_engages_on_tall_problems_only():
     o = dict(maxIter=2000, optTol=1e-10, randomize=False)
     f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
     f.set_gradient_cache(1)                      # the default, whatever CDH_GRADIENT_CACHE says
+    f.set_onchip_solve(False)                    # (256 columns: left on, the Gram form would take the path over after a few solves)
     x, xo = cd.SparseIterate(256), O.SparseIterate(256)
     for lam in lams:
         cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
@@ -1209,6 +1210,7 @@ def test_gradient_cache_default_mode_engages_on_tall_problems_only():
     rng, X, Y = _problem(62, 300, 900, 10)
     f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
     f.set_gradient_cache(1)
+    f.set_onchip_solve(False)
     x, xo = cd.SparseIterate(900), O.SparseIterate(900)
     served = []
     for lam in (0.5, 0.3, 0.2, 0.15, 0.1, 0.08):
