@@ -256,10 +256,11 @@ def cfg3_path(device=0, n=2_000_000, p=5000, nlam=100):
         f.close()
 
 
-def isolated_p2p_probe(cp, device, timeout_s=150):
-    """One child process per rank (same GPU, fresh rendezvous port) runs coordinatedescent.jl_amd/p2p_probe.py.
-    Returns (ok on every rank, info).  Nothing the children do can hurt this process: they are waited for with
-    a timeout and killed by PID if they overstay."""
+def isolated_exchange_probe(cp, device, what="p2p", timeout_s=150):
+    """One child process per rank (same GPU, fresh rendezvous port) runs coordinatedescent.jl_amd/p2p_probe.py in mode
+    `what` ("p2p": the direct exchange; "rccl": the communicator's bring-up and probe sums).  Returns (ok on every rank,
+    info).  Nothing the children do can hurt this process: they are waited for with a timeout and killed by PID if they
+    overstay."""
     import socket
     import struct
     import subprocess
@@ -279,10 +280,11 @@ def isolated_p2p_probe(cp, device, timeout_s=150):
     script = os.path.join(ROOT, "coordinatedescent.jl_amd", "p2p_probe.py")
     ok, info = False, {}
     try:
-        r = subprocess.run([sys.executable, script, str(device)], env=env, capture_output=True, text=True,
+        tag = "RCCL_PROBE_" if what == "rccl" else "P2P_PROBE_"
+        r = subprocess.run([sys.executable, script, str(device), what], env=env, capture_output=True, text=True,
                            timeout=timeout_s, cwd=ROOT)
-        line = [l for l in r.stdout.splitlines() if l.startswith("P2P_PROBE_")]
-        ok = r.returncode == 0 and bool(line) and line[-1].startswith("P2P_PROBE_OK")
+        line = [l for l in r.stdout.splitlines() if l.startswith(tag)]
+        ok = r.returncode == 0 and bool(line) and line[-1].startswith(tag + "OK")
         info = {"rc": r.returncode, "line": line[-1] if line else None}
         if ok:
             info["latency_us"] = float(line[-1].split()[1])
@@ -359,6 +361,9 @@ def main():
     ap.add_argument("--no-rccl", action="store_true",
                     help="TEST ONLY (ranks sharing one GPU, which RCCL refuses): build no communicator; with "
                          "--exchange rccl the timed region then has NO exchange and its numbers mean nothing")
+    ap.add_argument("--no-rccl-probe", action="store_true",
+                    help="at N > 1: build the RCCL communicator in this process without trying it in child processes first")
+    ap.add_argument("--rccl-probe-timeout", type=float, default=120.0, help="seconds the isolated RCCL bring-up may take")
     ap.add_argument("--no-exchange-trial", action="store_true",
                     help="with --exchange auto: skip the second region (same as --exchange rccl)")
     ap.add_argument("--no-cfg1", action="store_true", help="skip the cfg1 (n=1000, p=200) CPU-vs-GPU solve timing")
@@ -391,14 +396,23 @@ def main():
 
     f, bstar = cd.CDLeastSquaresLoss.generate(n_local, a.cols, seed=123, s=a.planted, noise=a.noise, dtype=dtype,
                                               device=device, n_total=a.rows, row_offset=row0)
-    exchange, exchange_fallback = "rccl", None
+    exchange, exchange_fallback, rccl_probe = "rccl", None, None
     if a.no_rccl:
         exchange = "none(test-only)"
     else:
         # the communicator is built AND probed (exact sums of three records) before anything is timed over it.  A run
         # whose RCCL cannot be built or sums wrongly still measures the sharded sweep -- over the host-staged exchange,
         # which needs nothing from the interconnect and is far slower -- and the line says so instead of dying
-        rccl_ok, why = sharded.connect_checked(f, cp)
+        # ... and before THAT, at N > 1, the same bring-up runs in child processes (one per rank, same GPUs, their own
+        # rendezvous): RCCL has never run across GPUs in this pipeline, and a ncclCommInitRank that never returns is waited
+        # for there with a timeout instead of taking this process -- and the result line -- with it
+        rccl_ok, why, rccl_probe = True, "", None
+        if cp.world > 1 and not a.no_rccl_probe:
+            rccl_ok, rccl_probe = isolated_exchange_probe(cp, device, "rccl", timeout_s=a.rccl_probe_timeout)
+            if not rccl_ok:
+                why = "isolated bring-up: " + str((rccl_probe or {}).get("line"))
+        if rccl_ok:
+            rccl_ok, why = sharded.connect_checked(f, cp)
         if not rccl_ok:
             f.comm_drop()
             sharded.connect_host(f, cp)
@@ -536,17 +550,19 @@ def main():
     res = result(exchange, dt, maxh, ev_ms, launches, alg_bytes)
     if exchange_fallback:
         res["exchange_fallback"] = {"wanted": "rccl", "used": exchange, "why": exchange_fallback}
+    if rccl_probe is not None:
+        res["rccl_bring_up_probe"] = rccl_probe
     if sparse is not None:
         res["sparse_regime"] = sparse
     if exch_us:
         res["exchange_latency_us"] = dict(exch_us, doubles=rec_doubles, how="200 back-to-back all-reduces, HIP events")
 
     # --exchange auto at N > 1.  The direct exchange has never run across GPUs in this pipeline, so its first
-    # contact with this machine happens in child processes (isolated_p2p_probe); this process only touches it
+    # contact with this machine happens in child processes (isolated_exchange_probe); this process only touches it
     # after every rank's probe came back clean, and otherwise reports the RCCL region as it is.
     run_trial = cp.world > 1 and a.exchange == "auto" and exchange != "p2p" and not a.no_exchange_trial
     if run_trial:
-        probe_ok, probe_info = isolated_p2p_probe(cp, device)
+        probe_ok, probe_info = isolated_exchange_probe(cp, device, "p2p")
         if not probe_ok:
             res["exchange_trial"] = {"exchange": "p2p", "probe": probe_info, "skipped": "the isolated probe did not validate on every rank"}
             run_trial = False

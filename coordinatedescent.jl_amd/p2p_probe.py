@@ -1,5 +1,12 @@
-"""First contact of the direct exchange (csrc/p2p_exchange.hpp) with a set of GPUs, in processes of its
-own: IPC handles over a private control plane, the mapped-inbox self-test, a few sharded sweeps whose
+"""First contact of an exchange with a set of GPUs, in processes of its own.  Two modes.
+
+`rccl`: the communicator of the row-sharded sweep -- unique id over a private control plane, ncclCommInitRank, three probe
+records whose exact sums every rank checks (sharded.connect_checked), then the sweeps and the latency probe below.  bench.py
+runs it before building its own communicator: RCCL has never run across GPUs in this pipeline, and a bring-up that never
+returns would otherwise take the whole run with it -- here it is waited for with a timeout.  Prints `RCCL_PROBE_OK <us>` or
+`RCCL_PROBE_FAILED <why>`.
+
+`p2p` (default): the direct exchange (csrc/p2p_exchange.hpp) -- IPC handles over a private control plane, the mapped-inbox self-test, a few sharded sweeps whose
 beta must be bit-identical on every rank, a latency probe.  bench.py runs one of these per rank (same
 GPUs, fresh rendezvous port) BEFORE its own process touches the direct exchange, so that whatever a
 never-validated transport can do on new hardware -- an IPC mapping error, a peer store that faults, a
@@ -7,7 +14,7 @@ hang -- happens here and costs nothing but this probe.  Prints `P2P_PROBE_OK <mi
 only if every rank validated every stage.
 
 usage (under the usual RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT environment):
-    python p2p_probe.py <device index>
+    python p2p_probe.py <device index> [p2p|rccl]
 """
 import os
 import sys
@@ -26,14 +33,22 @@ def main():
     sharded = import_module("coordinatedescent_jl_amd.sharded")
     cp = sharded.ControlPlane(backend="gloo")
     device = int(sys.argv[1]) if len(sys.argv) > 1 else cp.local_rank
+    what = sys.argv[2] if len(sys.argv) > 2 else "p2p"
+    tag = "RCCL_PROBE" if what == "rccl" else "P2P_PROBE"
     n_local, p = 65536, 128
     f, _ = cd.CDLeastSquaresLoss.generate(n_local, p, seed=7, s=8, noise=1.0, device=device,
                                           n_total=n_local * cp.world, row_offset=cp.rank * n_local)
-    ok, lat = False, float("nan")
+    ok, lat, why = False, float("nan"), ""
     try:
-        ok = sharded.connect_p2p(f, cp, selftest=True)
-    except Exception:
-        ok = False
+        if what == "rccl":
+            if os.environ.get("CDH_RCCL_PROBE_HANG"):  # TEST ONLY: stands in for a communicator whose construction never returns
+                import time
+                time.sleep(3600)
+            ok, why = sharded.connect_checked(f, cp)
+        else:
+            ok = sharded.connect_p2p(f, cp, selftest=True)
+    except Exception as e:
+        ok, why = False, str(e)[:200]
     if cp.sum_over_ranks(1.0 if ok else 0.0) == cp.world:
         try:
             f.set_sweep_mode("block", 64)
@@ -59,7 +74,7 @@ def main():
         cp.shutdown()
     except Exception:
         pass
-    print(("P2P_PROBE_OK %.2f" % lat) if ok_all else "P2P_PROBE_FAILED", flush=True)
+    print((tag + "_OK %.2f" % lat) if ok_all else (tag + "_FAILED " + (why or "a later stage")).rstrip(), flush=True)
     sys.exit(0 if ok_all else 4)
 
 

@@ -576,7 +576,10 @@ def test_bench_two_ranks_when_rccl_cannot_serve_them_still_measures_the_sharded_
     assert ja["n_gpus"] == 2 and ja["exchange_stats"]["nranks"] == 2
     if "exchange_fallback" in ja:
         fb = ja["exchange_fallback"]
-        assert fb["used"] == "host(gloo)" == ja["config"]["exchange"] and fb["why"].startswith("rank ")
+        # the bring-up was tried in child processes first (coordinatedescent.jl_amd/p2p_probe.py rccl) and failed THERE
+        assert fb["used"] == "host(gloo)" == ja["config"]["exchange"]
+        assert fb["why"].startswith("isolated bring-up: RCCL_PROBE_FAILED rank ") and "cdh_comm_init" in fb["why"]
+        assert ja["rccl_bring_up_probe"]["rc"] == 4
         assert ja["exchange_stats"]["host_calls"] > 0 and ja["exchange_stats"]["rccl_calls"] == 0
     else:
         assert ja["config"]["exchange"] == "rccl" and ja["exchange_stats"]["rccl_calls"] > 0
@@ -587,6 +590,29 @@ def test_bench_two_ranks_when_rccl_cannot_serve_them_still_measures_the_sharded_
     assert ja["config"]["moved_per_sweep"] == jb["config"]["moved_per_sweep"]
     assert abs(ja["config"]["last_maxH"] - jb["config"]["last_maxH"]) <= 1e-9 * abs(jb["config"]["last_maxH"])
     assert abs(ja["config"]["beta_abs_sum"] - jb["config"]["beta_abs_sum"]) <= 1e-9 * jb["config"]["beta_abs_sum"]
+
+
+def test_bench_an_rccl_bring_up_that_never_returns_costs_a_timeout_not_the_result_line():
+    """RCCL has never run across GPUs in this pipeline.  bench.py therefore tries the communicator's bring-up in child
+    processes first; here every child hangs in it (CDH_RCCL_PROBE_HANG, the stand-in for a ncclCommInitRank that never
+    returns): the children are killed at the timeout, the bench process never calls into RCCL, and the sharded sweep is
+    measured over the host-staged exchange -- one result line, with the reason on it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["CDH_RCCL_PROBE_HANG"] = "1"
+    a = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "300000",
+                        "--cols", "96", "--planted", "10", "--no-cpu-baseline", "--no-sparse", "--block", "16", "--no-exchange-trial",
+                        "--rccl-probe-timeout", "20"], capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert a.returncode == 0, (a.stdout[-1500:], a.stderr[-3000:])
+    got = [l for l in a.stdout.splitlines() if l.strip()]
+    assert len(got) == 1 and got[0].startswith("{"), got
+    ja = json.loads(got[0])
+    assert ja["n_gpus"] == 2 and ja["config"]["exchange"] == "host(gloo)" and ja["value"] > 0
+    assert ja["exchange_fallback"]["why"] == "isolated bring-up: timeout" and ja["rccl_bring_up_probe"]["rc"] is None
+    assert ja["exchange_stats"]["rccl_calls"] == 0 and ja["exchange_stats"]["host_calls"] > 0
 
 
 def test_bench_a_direct_exchange_probe_that_dies_costs_nothing():
