@@ -11,10 +11,12 @@ SURVEY's 1e-3 * lambda_max would leave 90% of the coordinates at zero.)
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME 10M x 1000
 problem with rows sharded across ranks (strong scaling), gradient scalars summed by an
-RCCL all-reduce inside the library: that region is always timed first.  With --exchange auto
-(the default) the direct exchange is then PROBED IN PROCESSES OF ITS OWN on the same GPUs
-(coordinatedescent.jl_amd/p2p_probe.py: whatever a transport that has never run on this
-hardware can do, it does there); only if every rank's probe validated are the same K steps timed
+RCCL all-reduce inside the library: that region is always timed first.  Both exchanges meet the
+machine IN PROCESSES OF THEIR OWN first, before this one has touched a GPU
+(coordinatedescent.jl_amd/p2p_probe.py rccl / p2p: whatever a transport that has never run on this
+hardware can do -- a bring-up that never returns, a faulting peer store -- it does there, under a
+timeout).  RCCL's probe failing: the sweep is measured over the host-staged exchange and the line says
+why.  With --exchange auto (the default), only if every rank's direct-exchange probe validated are the same K steps timed
 over it in this process, and `value` is the faster of the two if the direct one validated again
 (adopt_direct_exchange) -- the other timing is in `exchange_trial`.  --exchange rccl:
 RCCL only, nothing afterwards.
@@ -386,6 +388,18 @@ def main():
                  f"(run `python bench.py --gpus N` without a launcher, or make the two agree)")
     row0, n_local = sharded.shard_rows(a.rows, cp.rank, cp.world)
     dtype = np.float64 if a.dtype == "f64" else np.float32
+    # At N > 1 the exchanges meet this machine in child processes first -- neither RCCL nor the direct exchange has ever run
+    # across GPUs in this pipeline -- and they do so HERE, before this process has touched a GPU: a bring-up that never
+    # returns or a faulting peer store costs a timeout there, not this process and its result line; and the box never
+    # holds more than one process per rank on its GPUs at a time (nor the children's buffers next to this rank's shard).
+    probes = {}
+    if cp.world > 1:
+        import torch
+        dev0 = cp.local_rank % max(torch.cuda.device_count(), 1)     # (counts the devices without initialising one)
+        if not a.no_rccl and not a.no_rccl_probe:
+            probes["rccl"] = isolated_exchange_probe(cp, dev0, "rccl", timeout_s=a.rccl_probe_timeout)
+        if a.exchange == "auto" and not a.no_exchange_trial and probes.get("rccl", (True, None))[0]:
+            probes["p2p"] = isolated_exchange_probe(cp, dev0, "p2p")
     L = cd._lib.lib()
     ndev = cd._lib.C.c_int32()
     L.cdh_device_count(cd._lib.C.byref(ndev))
@@ -403,12 +417,10 @@ def main():
         # the communicator is built AND probed (exact sums of three records) before anything is timed over it.  A run
         # whose RCCL cannot be built or sums wrongly still measures the sharded sweep -- over the host-staged exchange,
         # which needs nothing from the interconnect and is far slower -- and the line says so instead of dying
-        # ... and before THAT, at N > 1, the same bring-up runs in child processes (one per rank, same GPUs, their own
-        # rendezvous): RCCL has never run across GPUs in this pipeline, and a ncclCommInitRank that never returns is waited
-        # for there with a timeout instead of taking this process -- and the result line -- with it
+        # ... and only if the same bring-up went through in the child processes above
         rccl_ok, why, rccl_probe = True, "", None
-        if cp.world > 1 and not a.no_rccl_probe:
-            rccl_ok, rccl_probe = isolated_exchange_probe(cp, device, "rccl", timeout_s=a.rccl_probe_timeout)
+        if "rccl" in probes:
+            rccl_ok, rccl_probe = probes["rccl"]
             if not rccl_ok:
                 why = "isolated bring-up: " + str((rccl_probe or {}).get("line"))
         if rccl_ok:
@@ -562,7 +574,7 @@ def main():
     # after every rank's probe came back clean, and otherwise reports the RCCL region as it is.
     run_trial = cp.world > 1 and a.exchange == "auto" and exchange != "p2p" and not a.no_exchange_trial
     if run_trial:
-        probe_ok, probe_info = isolated_exchange_probe(cp, device, "p2p")
+        probe_ok, probe_info = probes["p2p"] if "p2p" in probes else isolated_exchange_probe(cp, device, "p2p")
         if not probe_ok:
             res["exchange_trial"] = {"exchange": "p2p", "probe": probe_info, "skipped": "the isolated probe did not validate on every rank"}
             run_trial = False
