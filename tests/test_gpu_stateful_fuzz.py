@@ -130,7 +130,7 @@ def run_sequence(seed, setenv, ctx):
         return float(np.max(c)) / n
 
     for step in range(int(rng.integers(6, 12))):
-        op = int(rng.integers(0, 14))
+        op = int(rng.integers(0, 15))
         if op <= 4:                                    # a solve: warm (mostly) or cold, ordered or shuffled
             lam = lam_top() * float(rng.uniform(0.08, 0.95))
             o = dict(maxIter=4000, optTol=1e-12, randomize=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)),
@@ -208,6 +208,15 @@ def run_sequence(seed, setenv, ctx):
             cd.initialize_(f, x)
             O.initialize_(fo, xo)
             log.append(f"columns {j0}..{j0 + nc - 1} replaced")
+        elif op == 14:                                 # single visits through the operator interface (descendCoordinate!)
+            lam = lam_top() * float(rng.uniform(0.1, 0.9))
+            ks = rng.integers(1, p + 1, size=int(rng.integers(1, 6)))
+            log.append(f"descendCoordinate! k={ks.tolist()} lam={lam:.5g}")
+            for k in ks:
+                hg = cd.descendCoordinate_(f, cd.ProxL1(lam, om), x, int(k))
+                ho = O.descendCoordinate_(fo, O.ProxL1(lam, om), xo, int(k))
+                np.testing.assert_allclose(hg, ho, rtol=1e-7, atol=1e-12, err_msg="\n".join(log))
+            _check_iterates(x, xo, log)                            # (no dropzeros! in a single visit: zeros keep their slots)
         elif op >= 12 and kind == "ls":                # the front-ends on the SAME loss object (src/lasso.jl:229-260, 107-144)
             o = dict(maxIter=4000, optTol=1e-12, randomize=False, warmStart=True)
             if op == 12:
