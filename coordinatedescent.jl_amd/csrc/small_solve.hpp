@@ -1,22 +1,25 @@
 // small_solve.hpp -- the whole of _coordinateDescent! (coordinate_descent.jl:65-92) in ONE launch, for problems whose
-// design matrix is a few MB: a section of cdhip.hip kept in its own file (included once, inside cdhip.hip's anonymous
+// Gram matrix fits on chip (p <= 1024 columns): a section of cdhip.hip kept in its own file (included once, inside cdhip.hip's anonymous
 // namespace, after grad_cache.hpp, whose Gram-column scratch it borrows).
 //
 // Why: the reference's own test and benchmark shapes are n <= 3000 (test/lasso.jl:76-101, benchmark/cd_bench.jl:8-14).
 // There a column is 8-24 KB and a pass of the streamed sweep is launch latency and nothing else: BASELINE.json's cfg1
 // (n = 1000, p = 200) took 0.71 ms per solve in round 2 -- 8 passes x ~21 launches -- against 0.10 ms for ONE CPU core.
 //
-// How: for p <= 1024 and n p sz <= 16 MB the handle keeps the full Gram matrix G = X'X (X'WX with observation weights)
-// in HBM -- p / 32 launches of k_cross, once per X -- and a solve is: one dots pass for g = X'r (k_col_dots, which the
-// warm start needs anyway), then ONE wave runs the reference's state machine on (g, G): pass after pass, full or active,
+// How: for p <= 1024 the handle keeps the full Gram matrix G = X'X (X'WX with observation weights) in HBM -- p / 32
+// launches of k_cross, once per X; built at the first solve for up to 16 MB of X, and for longer columns once the streamed
+// solves have cost as much (small_applicable: rent or buy) -- and a solve is: g = X'y - G beta from the cached X'y (or one
+// dots pass for g = X'r where the caller vouches for r: cdh_solve), then ONE wave runs the reference's state machine on
+// (g, G): pass after pass, full or active,
 // ordered or shuffled (the documented splitmix64 substitute, sparse_iterate.hpp), the visits in covariance form
 //   b = g_k,  beta_k <- S(beta_k + b / a_k, lambda n omega_k / a_k)   (sqrt-lasso: the closed form on (b, a_k, r'r)),
 //   g <- g - h G_k,   r'r <- r'r - 2 h b + h^2 a_k,
 // with ProximalBase's SparseIterate bookkeeping (support in order of first becoming non-zero, zeros kept until
-// dropzeros!'s swap-with-last) replayed on the device by lane 0, because the ORDER of the support is the visit order of
+// dropzeros!'s swap-with-last) replayed on the device, because the ORDER of the support is the visit order of
 // the next active pass.  The 51 solves of a cold start (coordinate_descent.jl:24-37) run inside the same launch.
-// One host round trip per solve: beta, the support and the statistics come back; the residual learns of the moves
-// through the same deferred catch-up as the gradient cache's covariance-form visits (sync_r).
+// One host round trip per solve: beta, the support and the statistics come back (written by the kernel into pinned host
+// memory); the residual is left to be rebuilt when something reads it (r_lazy), or learns of the moves through the same
+// deferred catch-up as the gradient cache's covariance-form visits (sync_r).
 // A visit step evaluates 64 consecutive positions of the visit list at once against the current g: every position
 // before the first one that moves is settled exactly (g does not change until something moves), so a full pass over a
 // sparse iterate is a handful of steps, and an active pass is one step per visit.
