@@ -350,8 +350,8 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default=os.environ.get("CDH_BENCH_MODE", "block"), choices=["coord", "block"])
     ap.add_argument("--block", type=int, default=None, choices=[2, 4, 8, 16, 32, 64],
-                    help="visits per launch of the blocked sweep (default 32; 64 for row shards under 4e6 rows: "
-                         "half the exchanges per sweep)")
+                    help="visits per launch of the blocked sweep (default: 32 on one GPU; on row shards the faster of 32 "
+                         "and 64 in one untimed sweep each -- 64 halves the exchanges per sweep)")
     ap.add_argument("--graph", action="store_true", help="replay each pass from a captured hipGraph")
     ap.add_argument("--lam-frac", type=float, default=1e-6, help="lambda / lambda_max")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -432,6 +432,7 @@ def main():
             a.exchange, a.graph = "rccl", False      # no direct-exchange trial on top of a machine RCCL failed on; no graphs
     if cp.world > 1 and a.exchange == "p2p" and sharded.connect_p2p(f, cp):
         exchange = "p2p"
+    block_auto = a.block is None
     if a.block is None:
         # B = 32 streams fastest per visit on long shards (measured 13.0 vs 13.8 us per visit at 5e6 rows);
         # from 2.5e6 rows down the two widths tie and B = 64 halves the exchanges.  fp32 B = 64 has no
@@ -454,6 +455,24 @@ def main():
         return cd.cdPass_(x, f, g, visit)
 
     maxh = 0.0
+    width_trial = None
+    if block_auto and cp.world > 1 and a.mode == "block" and a.dtype == "f64" and exchange != "none(test-only)":
+        # On row shards the width is a trade between the streaming kernel (B = 32 is up to 4 % faster per visit on long
+        # shards) and the number of exchanges per sweep (B = 64 halves them), so what an exchange costs on THIS machine
+        # decides -- which nobody has measured yet.  One untimed sweep per width after a first use of it; the slower rank's
+        # time; every rank sees the same two numbers (collective max) and so makes the same choice.
+        width_trial = {}
+        for B in (32, 64):
+            f.set_sweep_mode("block", B)
+            step()
+            cp.barrier()
+            L.cdh_synchronize(f._h)
+            tw = time.perf_counter()
+            step()
+            L.cdh_synchronize(f._h)
+            width_trial[B] = cp.max_over_ranks(time.perf_counter() - tw)
+        a.block = min(width_trial, key=width_trial.get)
+        f.set_sweep_mode("block", a.block)
     for _ in range(a.warmup):
         step()
     cp.barrier()
@@ -542,7 +561,8 @@ def main():
                        "sweep_mode": a.mode + (str(a.block) if a.mode == "block" else ""), "graph": bool(a.graph),
                        "parallelism": f"rows{cp.world}",
                        "exchange": exchange if (cp.world > 1 or st["rccl_calls"] > 0) else None,
-                       "moved_per_sweep": moved, "last_maxH": maxh, "beta_abs_sum": float(np.abs(beta_timed).sum())},
+                       "moved_per_sweep": moved, "last_maxH": maxh, "beta_abs_sum": float(np.abs(beta_timed).sum()),
+                       **({"sweep_width_trial_ms": {str(k): v * 1e3 for k, v in width_trial.items()}} if width_trial else {})},
             # what the exchange itself reports: the communicator's rank count (ncclCommCount) and how many
             # all-reduces went through each transport since the handle was created (rank 0)
             "exchange_stats": st,
