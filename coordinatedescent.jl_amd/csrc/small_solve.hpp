@@ -223,13 +223,16 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
                 int islot = s_ind2slot[k], cslot_own = s_colslot[k];
                 // least squares: the threshold lambda0 omega_k (n / a_k) of visit_update (kernels.hpp), same expression, once per chunk
                 const double thr_ls = lambda0 * om * (n_total / a);
+                // ... and 1 / a_k once per chunk: a step then costs an fma where it cost a division (~35 instructions of a
+                // lone wave's ~180 per step); beta differs from the divided form in the last bit at most
+                const double inv_a = 1.0 / a;
                 int done = 0;
                 for (;;) {
                     VisitOut o{0.0, 0, 0};
                     if constexpr (SQRT) {
                         o = visit_update(1, lambda0, n_total, a, gk, q, oldv, om);
                     } else {
-                        const double v = oldv + gk / a;
+                        const double v = fma(gk, inv_a, oldv);
                         o.tch = (v != 0.0) ? 1 : 0;
                         o.nv = soft_threshold(v, thr_ls);
                     }
