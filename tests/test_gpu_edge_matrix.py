@@ -1,0 +1,79 @@
+"""Edge inputs x execution paths: every case below is solved through the one-launch solve and through the streamed kernels
+(per-coordinate, B = 32, B = 64) and compared with the oracle -- beta within 1e-9 (NaNs in the same number where a zero
+column makes the reference produce them), same pass count.  The inputs are the ones where a covariance-form or blocked
+formulation could plausibly part ways with the reference's visit-by-visit loop (src/cd_differentiable_function.jl:83-111,
+src/coordinate_descent.jl:7-39, 65-92): exactly collinear columns (a singular Gram matrix), y = 0, lambda above lambda_max,
+a nearly unpenalised dense solve, the cold start's numSteps at the one-launch path's limit and beyond, one column, two rows,
+p at and just past the one-launch limit, a zero penalty weight, a constant and a zero column, maxIter = 1, optTol = 0."""
+import numpy as np
+import pytest
+
+import coordinatedescent_jl_amd as cd
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _base(seed=5, n=400, p=40):
+    rng = np.random.default_rng(seed)
+    X = np.asfortranarray(rng.standard_normal((n, p)))
+    Y = X[:, :4] @ rng.standard_normal(4) + rng.standard_normal(n)
+    return rng, X, Y
+
+
+def _cases():
+    rng, X, Y = _base()
+    n, p = X.shape
+    Xd = X.copy(order="F"); Xd[:, 7] = Xd[:, 3]; Xd[:, 9] = -2.0 * Xd[:, 1]
+    yield "duplicate_columns", Xd, Y, 0.05, None, False, {}
+    yield "y_zero", X, np.zeros(n), 0.05, None, False, {}
+    yield "lambda_above_lambda_max", X, Y, 10.0, None, False, {}
+    yield "lambda_tiny_dense", X, Y, 1e-6, None, False, dict(maxIter=400)
+    yield "cold_numSteps_63", X, Y, 0.05, None, False, dict(warmStart=False, numSteps=63)
+    yield "cold_numSteps_64", X, Y, 0.05, None, False, dict(warmStart=False, numSteps=64)
+    yield "cold_numSteps_1", X, Y, 0.05, None, False, dict(warmStart=False, numSteps=1)
+    yield "sqrt_lambda_above_lambda_max", X, Y, 50.0, None, True, {}
+    yield "sqrt", X, Y, 2.0, None, True, {}
+    yield "n2_p5", np.asfortranarray(rng.standard_normal((2, 5))), rng.standard_normal(2), 0.1, None, False, {}
+    Xp = np.asfortranarray(rng.standard_normal((1500, 1024)))
+    yield "p1024", Xp, Xp[:, :5] @ rng.standard_normal(5) + rng.standard_normal(1500), 0.15, None, False, {}
+    Xq = np.asfortranarray(rng.standard_normal((600, 1025)))
+    yield "p1025", Xq, Xq[:, :5] @ rng.standard_normal(5) + rng.standard_normal(600), 0.2, None, False, {}
+    X1 = np.asfortranarray(rng.standard_normal((50, 1)))
+    yield "p1", X1, 2 * X1[:, 0] + 0.1 * rng.standard_normal(50), 0.1, None, False, {}
+    om = rng.uniform(0.5, 2, size=p); om[5] = 0.0
+    yield "zero_penalty_weight", X, Y, 0.05, om, False, {}
+    Xc = X.copy(order="F"); Xc[:, 11] = 3.0
+    yield "constant_column", Xc, Y, 0.05, None, False, {}
+    Xz = X.copy(order="F"); Xz[:, 0] = 0.0
+    yield "zero_first_column", Xz, Y, 0.05, None, False, {}
+    yield "maxIter_1", X, Y, 0.05, None, False, dict(maxIter=1)
+    yield "optTol_0", X, Y, 0.05, None, False, dict(optTol=0.0, maxIter=50)
+
+
+CASES = {c[0]: c[1:] for c in _cases()}
+
+
+@pytest.mark.parametrize("onchip", [True, False], ids=["one_launch", "streamed"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_edge_input_on_every_path(name, onchip, monkeypatch):
+    X, Y, lam, om, sqrt, extra = CASES[name]
+    monkeypatch.setenv("CDH_SMALL_PATH", "1" if onchip else "0")
+    o = dict(dict(maxIter=3000, optTol=1e-11, randomize=False), **extra)
+    p = X.shape[1]
+    for mode in (("coord", 2), ("block", 32), ("block", 64)):
+        f = (cd.CDSqrtLassoLoss if sqrt else cd.CDLeastSquaresLoss)(Y, X)
+        fo = (O.CDSqrtLassoLoss if sqrt else O.CDLeastSquaresLoss)(Y, X)
+        f.set_sweep_mode(*mode)
+        x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(**o))
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam, om), O.CDOptions(**o))
+        got, want = x.dense(), xo.dense()
+        assert int(np.isnan(got).sum()) == int(np.isnan(want).sum()), (name, mode)
+        ok = ~np.isnan(want)
+        np.testing.assert_allclose(got[ok], want[ok], rtol=0, atol=1e-9, err_msg=f"{name} {mode}")
+        assert f.last_stats["passes"] == st["passes"] and f.last_stats["converged"] == st["converged"], (name, mode, f.last_stats, st)
+        if onchip and mode[0] == "coord":      # which shapes the one-launch path takes: p <= 1024 columns, numSteps + 1 <= 64 solves
+            expected = p <= 1024 and o.get("numSteps", 50) + 1 <= 64
+            assert (f.onchip_stats()["solves"] > 0) == expected, (name, f.onchip_stats())
+        f.close()
