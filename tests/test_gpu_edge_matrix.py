@@ -77,3 +77,31 @@ def test_edge_input_on_every_path(name, onchip, monkeypatch):
             expected = p <= 1024 and o.get("numSteps", 50) + 1 <= 64
             assert (f.onchip_stats()["solves"] > 0) == expected, (name, f.onchip_stats())
         f.close()
+
+
+@pytest.mark.parametrize("onchip", [True, False], ids=["one_launch", "streamed"])
+@pytest.mark.parametrize("weights", ["some_zero", "all_equal", "scaled_1e6", "scaled_1e-6", "one_dominant"])
+def test_observation_weight_edges_on_every_path(weights, onchip, monkeypatch):
+    """CDWeightedLSLoss (src/cd_differentiable_function.jl:118-194) with weights that drop rows, scale the loss by 1e+-6
+    (a and b scale alike: the update does not, the threshold lambda n / a does), or let one observation dominate."""
+    rng, X, Y = _base(seed=8, n=500, p=48)
+    n, p = X.shape
+    w = {"some_zero": np.where(rng.random(n) < 0.3, 0.0, rng.uniform(0.5, 1.5, size=n)),
+         "all_equal": np.full(n, 0.7),
+         "scaled_1e6": 1e6 * rng.uniform(0.5, 1.5, size=n),
+         "scaled_1e-6": 1e-6 * rng.uniform(0.5, 1.5, size=n),
+         "one_dominant": np.r_[1e4, rng.uniform(0.5, 1.5, size=n - 1)]}[weights]
+    wy = np.abs(X.T @ (w * Y))
+    lam = 0.2 * float(np.max(wy)) / n
+    monkeypatch.setenv("CDH_SMALL_PATH", "1" if onchip else "0")
+    o = dict(maxIter=5000, optTol=1e-11, randomize=False)
+    for mode in (("coord", 2), ("block", 16), ("block", 64)):
+        f, fo = cd.CDWeightedLSLoss(Y, X, w), O.CDWeightedLSLoss(Y, X, w)
+        f.set_sweep_mode(*mode)
+        x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-9 * max(1.0, float(np.max(np.abs(xo.dense())))),
+                                   err_msg=f"{weights} {mode}")
+        assert f.last_stats["passes"] == st["passes"] and xo.nnz > 0, (weights, mode, f.last_stats, st)
+        f.close()
