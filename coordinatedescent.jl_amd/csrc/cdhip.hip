@@ -511,6 +511,24 @@ inline int64_t gc_rows_per_nnz(const cdh_handle_s* h) {
     return (c.cov && (c.d_scan || c.g.empty())) ? kGcRowsPerNnzDev : kGcRowsPerNnz;   // (before the first sizing: assume the device path)
 }
 
+// When the support has outgrown what the cache pays for.  Long columns: a support column costs 1/32 of a pass over X to fetch
+// and p doubles per move to apply, against the read of X a cached full pass saves -- the cache stands aside once n < 32 nnz
+// (400 nnz while the fold and the re-check ran on the host), and beyond kGcMaxSupport columns.  SHORT columns (a streamed
+// visit is launch-bound there: ~0.35 us as its share of a block of 64 whatever it reads, against ~0.13 us in covariance form,
+// and fetching a batch of columns is a pass over a small X) keep the cache whatever n / nnz is, up to kGcMaxSupportShort
+// columns: benchmark/cd_bench.jl's n = 3000, p = 5000 path down to 0.03 lambda_max (774 non-zeros) 0.204 -> 0.118 s with the
+// rule off below 512 columns, before the cap was raised.
+constexpr int kGcMaxSupportShort = 4096;
+constexpr size_t kGcShortColumnBytes = (size_t)1 << 20;
+inline bool gc_short_columns(const cdh_handle_s* h) {
+    return h->gc.cov && (h->gc.d_scan || h->gc.g.empty()) && (size_t)h->n * h->esz <= kGcShortColumnBytes;
+}
+inline bool gc_support_outgrown(const cdh_handle_s* h) {        // the rows-per-non-zero rule (modes 1 and 2)
+    if (h->gc.mode == 3 || gc_short_columns(h)) return false;
+    return h->x.nnz() * gc_rows_per_nnz(h) > h->n_total;
+}
+inline int64_t gc_max_support(const cdh_handle_s* h) { return gc_short_columns(h) ? kGcMaxSupportShort : kGcMaxSupport; }
+
 // every loss and both storage types (round 3); a weighted loss only once its weights are there (they are zero until
 // cdh_set_obs_weights: every a_k would be zero and nothing could be settled)
 inline bool gc_applicable(const cdh_handle_s* h) {

@@ -204,7 +204,7 @@ bool gc_ready_for_cov(cdh_handle h, const int64_t* idx0, int64_t m) {
     if (!c.cov || !c.valid || !gc_applicable(h) || !c.d_G) return false;
     // the same bounds the full passes keep (gc_full_pass): the cache only pays on tall problems, and g is carried
     // through a bounded number of covariance-form updates before it is taken afresh from X
-    if (c.mode != 3 && h->x.nnz() * gc_rows_per_nnz(h) > h->n_total) { gc_invalidate(h, false); return false; }
+    if (gc_support_outgrown(h)) { gc_invalidate(h, false); return false; }
     if (c.cov_since_ref > c.refresh_after && gc_rereference(h) != CDH_OK) return false;
     if (!c.moved.empty()) {
         for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return false;
@@ -609,10 +609,8 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     // paid that much in plain full passes on the same data: at most twice the cost of having known in advance
     const int64_t rent = std::max<int64_t>(kGcEngage, 1 + (3 * h->x.nnz()) / 64);
     if (!gc_applicable(h) || (c.mode == 1 && !c.valid && c.full_seen <= rent)) return CDH_OK;
-    // Folding a moved coordinate into g is p host flops (~0.5 ns each); reading X once is n p sz bytes at
-    // ~6 TB/s.  The cache only pays while nnz * p * 0.5 ns stays well under that, i.e. for n >> 400 nnz:
-    // short-and-wide problems (the reference's own n = 3000, p = 5000 shape) keep the dots-only screens.
-    if (c.mode != 3 && h->x.nnz() * gc_rows_per_nnz(h) > h->n_total) {
+    // the support has outgrown what the cache pays for (gc_support_outgrown, cdhip.hip: long columns only)
+    if (gc_support_outgrown(h)) {
         if (c.valid) gc_invalidate(h, false);
         return CDH_OK;
     }
@@ -620,7 +618,7 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     // below (rounding only ever accumulates in g; one dots-only pass resets it), or dropped if this pass turns
     // out to run the plain way -- the active passes that follow must not keep carrying it either
     const bool refresh_due = c.valid && c.cov_since_ref > c.refresh_after;
-    if (h->x.nnz() > kGcMaxSupport) { if (refresh_due) gc_invalidate(h, false); return CDH_OK; }
+    if (h->x.nnz() > gc_max_support(h)) { if (refresh_due) gc_invalidate(h, false); return CDH_OK; }
     if (c.cooldown > 0) { c.cooldown -= 1; if (c.valid) gc_invalidate(h, false); return CDH_OK; }
     CHK(gc_size(h));
     if (c.mode == 0) return CDH_OK;

@@ -1213,11 +1213,11 @@ def test_gradient_cache_random_configurations_match_oracle(seed):
     np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-8 * max(1.0, float(np.max(np.abs(Y)))))
 
 
-def test_gradient_cache_default_mode_engages_on_tall_problems_only():
-    """The default (mode 1): rent-or-buy, and only while the problem has enough rows per non-zero -- n >= 32 nnz now that
-    the fold and the certificate re-check run on the device (round 3; n >= 400 nnz while they were p host flops per
-    mover).  A tall path engages it and matches the oracle; on a short-and-wide problem the cache serves the sparse
-    head of the path and stands aside once the support has outgrown n / 32."""
+def test_gradient_cache_default_mode_engages_on_tall_problems_only(monkeypatch):
+    """The default (mode 1): rent-or-buy, and on LONG columns only while the problem has enough rows per non-zero -- n >= 32 nnz
+    now that the fold and the certificate re-check run on the device (round 3; n >= 400 nnz while they were p host flops per
+    mover).  A tall path engages it and matches the oracle; once the support has outgrown n / (rows per non-zero) the cache
+    stands aside.  SHORT columns (under 1 MB: a streamed visit is launch-bound there) keep it whatever n / nnz is."""
     rng, X, Y = _problem(61, 40_000, 256, 6, noise=1.0)
     lams = 0.5 * np.exp(np.linspace(0.0, np.log(0.05), 8))
     o = dict(maxIter=2000, optTol=1e-10, randomize=False)
@@ -1233,21 +1233,32 @@ def test_gradient_cache_default_mode_engages_on_tall_problems_only():
     cs = f.cache_stats()
     assert xo.nnz * 32 < 40_000 and cs["passes"] >= 5 and cs["reference_passes"] == 1 and cs["gram_columns"] >= xo.nnz, cs
     f.close()
-    rng, X, Y = _problem(62, 300, 900, 10)
-    f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
-    f.set_gradient_cache(1)
-    f.set_onchip_solve(False)
-    x, xo = cd.SparseIterate(900), O.SparseIterate(900)
-    served = []
-    for lam in (0.5, 0.3, 0.2, 0.15, 0.1, 0.08):
-        before = f.cache_stats()["passes"]
-        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
-        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
-        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
-        assert f.last_stats["passes"] == st["passes"]
-        served.append((x.nnz, f.cache_stats()["passes"] - before))
-    assert served[-1][0] * 32 > 300 and served[-1][1] == 0, served     # the support outgrew n / 32: no pass from the cache
-    f.close()
+
+    def path(n, p, seed, lams_, s=10):
+        rng, X, Y = _problem(seed, n, p, s)
+        f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+        f.set_gradient_cache(1)
+        f.set_onchip_solve(False)
+        x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+        served = []
+        for lam in lams_:
+            before = f.cache_stats()["passes"]
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+            st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+            np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+            assert f.last_stats["passes"] == st["passes"]
+            served.append((x.nnz, f.cache_stats()["passes"] - before))
+        f.close()
+        return served
+    # long columns (1.1 MB), the rule tightened to 16 000 rows per non-zero so that a small support outgrows it
+    monkeypatch.setenv("CDH_GC_ROWS_PER_NNZ", "16000")
+    served = path(140_000, 48, 62, (0.5, 0.3, 0.2, 0.1, 0.05, 0.03))
+    assert served[-1][0] * 16000 > 140_000 and served[-1][1] == 0, served     # the support outgrew the rule: no pass from the cache
+    assert any(sv > 0 for nz, sv in served if nz * 16000 <= 140_000), served  # ... which served the head of the path
+    # short columns: the same rule would have switched the cache off at nnz > 300 / 32; it stays on
+    monkeypatch.delenv("CDH_GC_ROWS_PER_NNZ")
+    served = path(300, 900, 62, (0.5, 0.3, 0.2, 0.15, 0.1, 0.08))
+    assert served[-1][0] * 32 > 300 and served[-1][1] > 0, served
 
 
 @pytest.mark.parametrize("loss", ["ls", "sqrt"])
