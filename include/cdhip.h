@@ -203,9 +203,10 @@ int32_t cdh_set_screening(cdh_handle h, int32_t on);
  * times on one X.  mode: 0 off; 1 (default) engages once the handle has run as many screened full passes on
  * the same data as the Gram columns of its support cost to fetch (at least three; a cold start engages at
  * once); 2 from the first full pass (what a path driver that knows it has 100 lambdas to go asks for).
- * Modes 1 and 2 engage only while n_total >= 32 * nnz(x) (round 3: the fold of a move into the gradient and the re-check
- * of skipped certificates run on the device; while they were p host flops per mover the bound was 400): a support that
- * large makes most visits real ones anyway; mode 3 is mode 2 without that guard (tests).
+ * On columns of 1 MB and more, modes 1 and 2 engage only while n_total >= 32 * nnz(x) (round 3: the fold of a move into the
+ * gradient and the re-check of skipped certificates run on the device; while they were p host flops per mover the bound was
+ * 400): a support that large makes most visits real ones anyway; mode 3 is mode 2 without that guard (tests).  Shorter
+ * columns keep the cache whatever n / nnz is (a streamed visit is launch-bound there and loses to the covariance form).
  * Same iterates, support order and pass counts as visiting every coordinate.
  * While the cache is engaged the visits themselves need no read of X either (least squares, sqrt-lasso): the block
  * record the scalar-update kernel consumes -- X_k'r, the Gram entries between the block's coordinates -- is
