@@ -46,6 +46,10 @@ int32_t gc_size(cdh_handle h) {   // first use on this handle
     const int64_t nsuper = (launches + kGramWaves - 1) / kGramWaves;   // a block's four waves take four column groups
     c.cross_GX = (int)std::max<int64_t>(1, std::min<int64_t>(nsuper, gxe ? atoi(gxe) : 4));
     c.cross_J = (int)std::max<int64_t>(1, std::min<int64_t>(nslabs, ((int64_t)kCrossOcc * h->cus) / c.cross_GX));
+    // short columns have few row slabs to hand out (n = 3000: two): the resident blocks they leave unused take further
+    // column super-groups instead (benchmark/cd_bench.jl's shape: 8 blocks walked 79 column groups, 0.78 ms per batch of a
+    // 120 MB X; 40 blocks: one group per wave)
+    if (!gxe) c.cross_GX = (int)std::min<int64_t>(nsuper, std::max<int64_t>(c.cross_GX, ((int64_t)kCrossOcc * h->cus) / c.cross_J));
     // (a handle whose first sizing failed may be asked again: what a failed attempt got was freed below)
     bool fits = hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec) == hipSuccess &&
                 hipMalloc((void**)&c.d_cross_part, sizeof(double) * (size_t)launches * (size_t)c.cross_J * kCrossRec) == hipSuccess &&
@@ -225,10 +229,9 @@ template <int NG> int32_t launch_cov_chunk(cdh_handle h, int m, bool chk = false
     GradCache& c = h->gc;
     for (int pos0 = 0; pos0 < m; pos0 += B) {
         const int nb = std::min(B, m - pos0);
-        hipLaunchKernelGGL((k_cov_record<NG>), dim3(1), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot, h->p, h->d_idx, pos0, nb,
-                           h->d_ctrl, h->d_red);
-        hipLaunchKernelGGL((k_gram_scalar<NG>), dim3(1), dim3(64), 0, h->stream, h->d_red, nb, h->chunk_dup ? 1 : 0, h->d_ctrl,
-                           h->beta, h->omega, h->d_idx, h->d_hs, h->d_newval, h->d_touched, pos0, c.d_qs);
+        hipLaunchKernelGGL((k_cov_block<NG>), dim3(1), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot, h->p, h->d_idx, pos0, nb,
+                           h->chunk_dup ? 1 : 0, h->d_ctrl, h->beta, h->omega, h->d_hs, h->d_newval, h->d_touched, c.d_qs,
+                           h->d_red + R::OFF_Q);
         if (chk)
             hipLaunchKernelGGL(k_cov_gupdate_chk, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot,
                                c.d_a, h->omega, h->d_ctrl, h->p, h->d_idx, h->d_hs, c.d_qs, c.d_upos, c.d_pos_of, c.d_setflag,

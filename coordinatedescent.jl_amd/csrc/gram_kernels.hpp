@@ -433,16 +433,16 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // G's column, 1/a and the threshold are fetched / computed by all lanes before it, and maxH,
 // the touched flags and the stores come after it.  `dup` says a coordinate may repeat inside
 // the block (only caller-supplied visit lists can do that): later visits then see the new value.
+// (the body is shared with k_cov_block below, where the record sits in LDS and wave 0 of a wider block runs it)
 template <int NG>
-__global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ rec_g, int nb, int dup,
-                                                    Ctrl* ctrl, double* beta,
-                                                    const double* __restrict__ omega,
-                                                    const int64_t* __restrict__ idx, double* hs,
-                                                    double* newval, int32_t* touched, int pos0,
-                                                    double* qs = nullptr /* sqrt-lasso: r'r after each visit */) {
+__device__ __forceinline__ void gram_scalar_body(const double* __restrict__ rec_g, int nb, int dup,
+                                                 Ctrl* ctrl, double* beta,
+                                                 const double* __restrict__ omega,
+                                                 const int64_t* __restrict__ idx, double* hs,
+                                                 double* newval, int32_t* touched, int pos0,
+                                                 double* qs /* sqrt-lasso: r'r after each visit */, const int lane) {
     using R = GramRec<NG>;
     constexpr int B = R::B;
-    const int lane = threadIdx.x;
     const bool mine = lane < nb;
     const int li = mine ? lane : 0;
     // independent loads first: this lane's column of G, c, a, the iterate and the weights
@@ -539,6 +539,15 @@ __global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ r
         if (last) beta[k_me] = nv_me;
         if (qs && loss == 1) qs[pos0 + lane] = q_me;
     }
+}
+template <int NG>
+__global__ __launch_bounds__(64) void k_gram_scalar(const double* __restrict__ rec_g, int nb, int dup,
+                                                    Ctrl* ctrl, double* beta,
+                                                    const double* __restrict__ omega,
+                                                    const int64_t* __restrict__ idx, double* hs,
+                                                    double* newval, int32_t* touched, int pos0,
+                                                    double* qs = nullptr /* sqrt-lasso: r'r after each visit */) {
+    gram_scalar_body<NG>(rec_g, nb, dup, ctrl, beta, omega, idx, hs, newval, touched, pos0, qs, (int)threadIdx.x);
 }
 
 // Cross products of ALL p columns with up to 32 columns (B) in ONE launch, one pass over X:
@@ -775,34 +784,42 @@ __global__ __launch_bounds__(256) void k_cross_reduce(const double* __restrict__
 // ---- covariance-form visits (cdhip.hip / grad_cache.hpp, "cov chunks") --------------------------------------
 // While the gradient cache holds g = X'r and the Gram columns G_j = X'X_j of every coordinate of a chunk,
 // the block record k_gram_scalar consumes -- c_i = X_ki'r, G_si = X_ks'X_ki, a_i = G_ii -- can be read off
-// the cache instead of being streamed from X: no HBM traffic for the visit at all.  k_cov_record gathers the
-// record of visits [pos0, pos0 + nb); k_gram_scalar runs the same B sequential updates as in the streamed
+// the cache instead of being streamed from X: no HBM traffic for the visit at all.  k_cov_block gathers the
+// record of visits [pos0, pos0 + nb) and runs the same B sequential updates as in the streamed
 // sweep; k_cov_gupdate then applies g -= sum_i h_i G_ki to all p entries.  The residual is brought up to
 // date later, once (k_multi_axpy over the coordinates that moved).  Least squares and sqrt-lasso (whose r'r
 // travels from block to block in the control block: q <- q - 2 h b + h^2 a, the recurrence the streamed
 // blocks use inside a block), fp64.
+// k_cov_block: gathers the record of visits [pos0, pos0 + nb) -- G[s][j] for s <= j < nb, c_j = g_kj, the carried r'r -- into
+// LDS with the whole block, then wave 0 runs k_gram_scalar's B sequential updates on it (one launch: the covariance-form
+// blocks are launch latency and little else; rounds 2-3 had the gather in a kernel of its own, k_cov_record, 2.5 - 7.5 us
+// per block).  Same arithmetic in the same order.
 template <int NG>
-__global__ __launch_bounds__(256) void k_cov_record(const double* __restrict__ g, const double* __restrict__ Gcols,
-                                                    const int32_t* __restrict__ slot, int64_t p,
-                                                    const int64_t* __restrict__ idx, int pos0, int nb,
-                                                    const Ctrl* ctrl, double* __restrict__ rec) {
+__global__ __launch_bounds__(256) void k_cov_block(const double* __restrict__ g, const double* __restrict__ Gcols,
+                                                   const int32_t* __restrict__ slot, int64_t p,
+                                                   const int64_t* __restrict__ idx, int pos0, int nb, int dup,
+                                                   Ctrl* ctrl, double* beta, const double* __restrict__ omega,
+                                                   double* hs, double* newval, int32_t* touched, double* qs,
+                                                   double* __restrict__ q_block /* r'r the block starts from: k_cov_gupdate_chk reads it */) {
     using R = GramRec<NG>;
     constexpr int B = R::B;
     __shared__ int64_t s_k[B];
     __shared__ int64_t s_off[B];
+    __shared__ double s_rec[R::N];
     for (int i = threadIdx.x; i < B; i += blockDim.x) {
         const int64_t k = idx[pos0 + (i < nb ? i : 0)];
         s_k[i] = k;
         s_off[i] = (int64_t)slot[k] * p;
     }
     __syncthreads();
-    // G[s][j] for s <= j < nb (what k_gram_scalar reads: column j above the diagonal, and the diagonal)
     for (int e = threadIdx.x; e < B * B; e += blockDim.x) {
         const int sI = e / B, j = e % B;
-        if (sI <= j && j < nb) rec[R::g(sI, j)] = Gcols[s_off[j] + s_k[sI]];
+        if (sI <= j && j < nb) s_rec[R::g(sI, j)] = Gcols[s_off[j] + s_k[sI]];
     }
-    for (int i = threadIdx.x; i < B; i += blockDim.x) rec[R::OFF_C + i] = (i < nb) ? g[s_k[i]] : 0.0;
-    if (threadIdx.x == 0) rec[R::OFF_Q] = ctrl->q_carry;   // r'r (read by the sqrt-lasso update only): carried, never re-read from r
+    for (int i = threadIdx.x; i < B; i += blockDim.x) s_rec[R::OFF_C + i] = (i < nb) ? g[s_k[i]] : 0.0;
+    if (threadIdx.x == 0) { const double q0 = ctrl->q_carry; s_rec[R::OFF_Q] = q0; *q_block = q0; }
+    __syncthreads();
+    if (threadIdx.x < 64) gram_scalar_body<NG>(s_rec, nb, dup, ctrl, beta, omega, idx, hs, newval, touched, pos0, qs, (int)threadIdx.x);
 }
 
 // ---- a whole full pass from the cache, on the device (grad_cache.hpp: gc_pass_device) ------------------------------
