@@ -1014,9 +1014,11 @@ int32_t solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched, cd
     return CDH_OK;
 }
 
-int32_t lambda_max(cdh_handle h, double* out) {
+int32_t lambda_max(cdh_handle h, double* out, std::vector<double>* dots = nullptr /* the (X_k'r, a_k) pairs, for a caller that can use them */) {
     CHK(col_dots(h, 0, h->p, h->r, h->loss == CDH_WLS));
-    std::vector<double> cd((size_t)(2 * h->p));
+    std::vector<double> cd_own;
+    std::vector<double>& cd = dots ? *dots : cd_own;
+    cd.resize((size_t)(2 * h->p));
     HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * h->p, hipMemcpyDeviceToHost, h->stream));
     double denom = (double)h->n_total;
     if (h->loss == CDH_SQRT) {
@@ -1547,7 +1549,9 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
             // 51 solves on the same X follow: the gradient cache (mode 1) need not wait for evidence
             h->gc.full_seen = std::max<int64_t>(h->gc.full_seen, 1000);
             double lmax = 0.0;
-            CHK(lambda_max(h, &lmax));                  // _findLambdaMax        (:29)
+            std::vector<double> dots;
+            CHK(lambda_max(h, &lmax, &dots));           // _findLambdaMax        (:29)
+            CHK(gc_adopt_dots(h, dots));                // ... whose pass over X is the cache's reference pass as well
             st.lambda_max = lmax;
             const double l1 = std::log(lmax), l2 = std::log(target);
             const double step = (l2 - l1) / (double)opt->numSteps;

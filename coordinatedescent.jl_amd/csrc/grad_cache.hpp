@@ -355,6 +355,27 @@ int32_t gc_validate(cdh_handle h) {
     return CDH_OK;
 }
 
+// The dots of all p columns with the residual as it stands have just been taken for another purpose (_findLambdaMax at the
+// head of a cold start, coordinate_descent.jl:29, right after initialize!): that pass over X is a reference pass the cache
+// need not repeat.  `cd`: (X_k'W r, X_k'W X_k) pairs as col_dots leaves them.
+int32_t gc_adopt_dots(cdh_handle h, const std::vector<double>& cd) {
+    GradCache& c = h->gc;
+    if (!gc_applicable(h) || c.mode == 0 || (int64_t)cd.size() != 2 * h->p) return CDH_OK;
+    CHK(gc_size(h));
+    if (c.mode == 0 || c.g.empty()) return CDH_OK;
+    const bool beta_known = c.beta_ok;
+    std::vector<double> beta_keep;
+    if (beta_known) beta_keep = c.beta_ref;
+    gc_invalidate(h, false);
+    for (int64_t k = 0; k < h->p; ++k) { c.g[(size_t)k] = cd[(size_t)(2 * k)]; c.a[(size_t)k] = cd[(size_t)(2 * k + 1)]; }
+    c.valid = true;
+    c.g_host_ok = true; c.g_dev_ok = false; c.a_dev_ok = false;
+    c.cov_since_ref = 0;
+    c.beta_ok = beta_known;
+    if (beta_known) c.beta_ref.swap(beta_keep);
+    return CDH_OK;
+}
+
 // Take g afresh from X (one dots-only pass) and MEASURE how far the carried g had drifted from it:
 //   drift = max_k |g_carried[k] - X_k'r| / thr_k   (thr_k: the threshold the certificates compare |g_k| with)
 // -- the quantity the certificates' relative margin must cover.  Pending moves are folded first so that both sides
