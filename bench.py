@@ -143,6 +143,10 @@ def cpu_baseline(f, n, lam, visits_target_s=12.0):
         t0 = time.perf_counter()
         L.cdo_bench_ls_visits(n, ncol, O._ptr(X), n, O._ptr(r), O._ptr(beta), lam, ncol, threads)
         per = (time.perf_counter() - t0) / ncol
+        if threads == 1:
+            # exactly the first `ncol` visits of a cyclic sweep from beta = 0, r = y: what the timed GPU sweep's first
+            # block of visits computes at full n (main() compares the two)
+            out["first_cycle_beta"] = beta.copy()
         visits = int(max(ncol, min(4096, visits_target_s / per)) // ncol * ncol)
         t0 = time.perf_counter()
         L.cdo_bench_ls_visits(n, ncol, O._ptr(X), n, O._ptr(r), O._ptr(beta), lam, visits, threads)
@@ -437,7 +441,8 @@ def main():
         # B = 32 streams fastest per visit on long shards (measured 13.0 vs 13.8 us per visit at 5e6 rows);
         # from 2.5e6 rows down the two widths tie and B = 64 halves the exchanges.  fp32 B = 64 has no
         # LDS-transposed variant (it would spill) and runs far below B = 32.
-        a.block = 32 if (cp.world == 1 or a.dtype == "f32" or n_local >= 4_000_000) else 64
+        # (decided from a.rows // world, the same number on every rank: near-equal shards may straddle a cut on n_local)
+        a.block = 32 if (cp.world == 1 or a.dtype == "f32" or a.rows // cp.world >= 4_000_000) else 64
     f.set_sweep_mode(a.mode, a.block)
     f.set_use_graph(a.graph)
     x = cd.SparseIterate(a.cols)
@@ -487,6 +492,24 @@ def main():
     dt = cp.max_over_ranks(time.perf_counter() - t0)
     ev_ms, launches, alg_bytes = f.profile_end()
     beta_timed, moved = x.dense().copy(), int(x.nnz)
+    # the same K steps once more with every pass replayed from a captured hipGraph (north_star names it; measured
+    # neutral on long columns: the stream is GPU-bound, not launch-bound).  Informational, never `value`; one GPU only.
+    graph_trial = None
+    if cp.world == 1 and not a.graph:
+        try:
+            f.set_use_graph(True)
+            step()                          # the capture
+            L.cdh_synchronize(f._h)
+            tg = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            L.cdh_synchronize(f._h)
+            graph_trial = {"graph_ms_per_step": (time.perf_counter() - tg) / a.steps * 1e3,
+                           "max_abs_dbeta_vs_timed": float(np.max(np.abs(x.dense() - beta_timed)))}
+        except Exception as e:              # informational: never costs the result line
+            graph_trial = {"error": str(e)[:200]}
+        finally:
+            f.set_use_graph(False)
     # the record one exchange carries in this sweep mode (4 doubles per coordinate; c, G, q per block)
     rec_doubles = {16: 273, 32: 801, 64: 2625}.get(a.block, 4 * a.block) if a.mode == "block" else 4
     exch_us = {}
@@ -588,6 +611,9 @@ def main():
         res["sparse_regime"] = sparse
     if exch_us:
         res["exchange_latency_us"] = dict(exch_us, doubles=rec_doubles, how="200 back-to-back all-reduces, HIP events")
+    if graph_trial is not None:
+        res["graph_ms_per_step"] = graph_trial.get("graph_ms_per_step")
+        res["graph_trial"] = graph_trial
 
     # --exchange auto at N > 1.  The direct exchange has never run across GPUs in this pipeline, so its first
     # contact with this machine happens in child processes (isolated_exchange_probe); this process only touches it
@@ -665,6 +691,14 @@ def main():
             cb = cpu_baseline(f, n_local, g.lambda0)
             res["cpu_baseline"] = cb[1]
             res["parity_vs_cpu_port"] = cb.pop("parity")
+            # the TIMED sweep's own output against the CPU port at full n: its first 32 visits (beta = 0, r = y, columns
+            # 1..32 in order) are exactly the port's first cycle over the 32-column slice
+            first = cb.pop("first_cycle_beta")
+            nfirst = min(len(first), a.cols)
+            diff = float(np.max(np.abs(beta_timed[:nfirst] - first[:nfirst])))
+            res["timed_sweep_parity"] = {"max_abs_beta_diff_first_32_visits": diff, "tolerance": 1e-10, "ok": bool(diff <= 1e-10),
+                                         "sample": f"beta of the timed sweep (n={n_local}, {a.mode}{a.block if a.mode == 'block' else ''}) after its "
+                                                   f"first {nfirst} visits vs the CPU port's first cycle over the same columns from r = y"}
             mt = [v for k, v in cb.items() if k != 1]
             if mt:
                 res["cpu_baseline_all_cores"] = mt[0]

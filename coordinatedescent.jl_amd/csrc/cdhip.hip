@@ -212,6 +212,11 @@ struct cdh_handle_s {
     std::vector<double> h_omega;  // host copy of the penalty weights (thresholds, objective)
     cdh::SupportList x;
     int mode = CDH_SWEEP_BLOCK, blockB = 32;   // the default (cdh_create: 64 on short fp64 columns); cdh_set_sweep_mode changes it
+    // The default width is chosen from the rank-LOCAL row count, and near-equal row shards can fall on opposite sides of the
+    // cut (n_total = 524287 over two ranks: 262144 and 262143 rows) -- ranks with different B would issue different numbers
+    // and sizes of all-reduces per pass.  So a sharded handle that still has its default agrees on it through the exchange
+    // before its first streamed chunk (agree_default_width): 64 only if every rank chose 64.
+    bool width_default = true, width_agreed = false;
     bool use_graph = false;
     int screening = 1;            // 0 never, 1 the solves' full passes over sparse iterates, 2 cdh_pass too
     bool reuse_residual = false;  // warm starts skip initialize! when r is known to match beta
@@ -790,7 +795,18 @@ template <typename T> int32_t launch_coord_chunk(cdh_handle h, int m) {
     return CDH_OK;
 }
 
+int32_t all_ranks_agree(cdh_handle h, bool mine, bool* all);   // grad_cache.hpp
+int32_t agree_default_width(cdh_handle h) {
+    if (h->width_agreed || !h->width_default || !sharded(h) || h->nranks <= 1) return CDH_OK;
+    bool all64 = false;
+    CHK(all_ranks_agree(h, h->blockB == 64, &all64));
+    if (!all64) h->blockB = 32;      // some shard is on the long side of the cut: every rank takes the long-column width
+    h->width_agreed = true;
+    return CDH_OK;
+}
+
 int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
+    CHK(agree_default_width(h));
     CHK(sync_r(h));   // the streaming kernels read and write r
     if (h->p2p_epoch >= kEpochSoftWrap) h->p2p_epoch = (h->p2p_epoch & 1u) ? 1u : 2u;   // slot parity keeps alternating
     std::memcpy(h->h_idx, idx0, sizeof(int64_t) * (size_t)m);
@@ -1701,7 +1717,7 @@ int32_t cdh_set_sweep_mode(cdh_handle h, int32_t mode, int32_t block) {
     if (mode == CDH_SWEEP_BLOCK && block != 2 && block != 4 && block != 8 && block != 16 && block != 32 && block != 64)
         return fail(h, CDH_BAD_ARG, "block size must be 2, 4, 8, 16, 32 or 64");
     h->mode = mode;
-    if (mode == CDH_SWEEP_BLOCK) h->blockB = block;
+    if (mode == CDH_SWEEP_BLOCK) { h->blockB = block; h->width_default = false; }   // the caller's choice: the caller keeps the ranks alike
     return CDH_OK;
 }
 
@@ -1807,6 +1823,7 @@ int32_t cdh_comm_init(cdh_handle h, const void* id_128_bytes, int32_t rank, int3
         return CDH_RCCL_ERROR;
     }
     h->rank = rank; h->nranks = nranks;
+    h->lost_exchange = false;          // an exchange is installed again (after a drop: cdh_comm_drop)
     return CDH_OK;
 }
 
@@ -1881,6 +1898,7 @@ int32_t cdh_p2p_enable(cdh_handle h, int32_t on) {
     if (on && *(volatile int*)h->p2p_timeout)
         return fail(h, CDH_RCCL_ERROR, "p2p exchange timed out earlier on this handle; it stays off");
     h->p2p_on = on != 0;
+    if (h->p2p_on) h->lost_exchange = false;   // the direct exchange serves the shard again
     return CDH_OK;
 }
 

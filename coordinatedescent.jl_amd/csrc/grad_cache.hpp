@@ -624,10 +624,22 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
     return CDH_OK;
 }
 
-// A full pass over idx0[0..m) from the cache.  *handled = false: the caller runs the pass the plain way.
-int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, bool* handled) {
+// Everything a cache-served full pass does before it looks at its visit list: the engagement policy, the sizing, a current g
+// (re-reference when there is none or the carried one is due; the Gram columns of the support and of what has moved,
+// the last batch filled with the inactive coordinates nearest their threshold; the fold) and ||r|| for the sqrt-lasso.
+// *go = false: the pass runs the plain way.  Shared by gc_full_pass and the device-resident solve (cov_solve.hpp).
+struct GcThresholds {             // the certificates' bounds as the host evaluates them (k_cov_scan's, on the host)
+    cdh_handle h; double lam, nt, rnorm, cert_abs;
+    double thr_of(int64_t k) const {
+        const double w = h->has_omega ? h->h_omega[(size_t)k] : 1.0;
+        return (h->loss == CDH_SQRT ? lam * w * rnorm : lam * nt * w) * (1.0 - 1e-9);
+    }
+    double cert(int64_t k) const { return thr_of(k) - cert_abs * std::sqrt(h->gc.a[(size_t)k]); }
+    double ratio(int64_t k) const { return std::fabs(h->gc.g[(size_t)k]) / thr_of(k); }
+};
+int32_t gc_prepare_full(cdh_handle h, bool* go, double* cert_abs_out) {
     GradCache& c = h->gc;
-    *handled = false;
+    *go = false;
     c.full_seen += 1;
     // mode 1 buys the Gram columns of the support (1.5 passes over X per 32 of them) only after the handle has
     // paid that much in plain full passes on the same data: at most twice the cost of having known in advance
@@ -648,8 +660,7 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     if (c.mode == 0) return CDH_OK;
     double cert_abs = 0.0;            // fp32 storage: what the certificates allow for the residual's rounding
     CHK(gc_cert_abs(h, &cert_abs));
-    const double lam = h->ctrl.lambda0, nt = (double)h->n_total;
-    const std::vector<double>& om = h->h_omega;
+    *cert_abs_out = cert_abs;
     // 1. a current g: fold the pending moves, fetching the columns that are missing; too many missing (or no
     //    reference yet, or the carried one is due): one dots-only pass over X gives a fresh g instead
     //    (re-referencing keeps what is known about beta: g will describe the same residual, only freshly summed)
@@ -661,6 +672,45 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     if (!c.valid || refresh_due) CHK(gc_rereference(h));
     for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_)       // the support moves in every pass: its columns first
         if (c.slot[(size_t)h->x.coord(s_)] < 0) want.push_back(h->x.coord(s_));
+    if (!want.empty()) {
+        // fill the last batch of 32 with the inactive coordinates nearest their threshold: the likeliest to
+        // enter the support next (on a lambda path: at one of the next lambdas)
+        const size_t room = (kCrossB - want.size() % kCrossB) % kCrossB;
+        if (room > 0 && c.moved.empty()) {
+            CHK(gc_need_host_g(h));
+            GcThresholds T{h, h->ctrl.lambda0, (double)h->n_total, 0.0, cert_abs};
+            if (h->loss == CDH_SQRT) { CHK(gc_ensure_q(h)); T.rnorm = std::sqrt(c.q); }
+            std::vector<std::pair<double, int64_t>> near;
+            for (int64_t k = 0; k < h->p; ++k)
+                if (c.slot[(size_t)k] < 0 && h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0)
+                    near.emplace_back(std::fabs(c.g[(size_t)k]) / T.thr_of(k), k);
+            const size_t take = std::min(room, near.size());
+            std::partial_sort(near.begin(), near.begin() + (std::ptrdiff_t)take, near.end(), std::greater<std::pair<double, int64_t>>());
+            for (size_t i = 0; i < take; ++i) want.push_back(near[i].second);
+        }
+        CHK(gc_fetch(h, want));
+        if (c.mode == 0) return CDH_OK;
+    }
+    for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return fail(h, CDH_BAD_ARG, "gradient cache: a moved coordinate has no Gram column");
+    gc_fold(h);
+    if (!c.valid) return CDH_OK;      // (a device fold that failed hard leaves no gradient: the pass runs the plain way)
+    if (h->loss == CDH_SQRT) CHK(gc_ensure_q(h));
+    *go = true;
+    return CDH_OK;
+}
+
+// A full pass over idx0[0..m) from the cache.  *handled = false: the caller runs the pass the plain way.
+int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, bool* handled) {
+    GradCache& c = h->gc;
+    *handled = false;
+    double cert_abs = 0.0;
+    {
+        bool go = false;
+        CHK(gc_prepare_full(h, &go, &cert_abs));
+        if (!go) return CDH_OK;
+    }
+    const double lam = h->ctrl.lambda0, nt = (double)h->n_total;
+    const std::vector<double>& om = h->h_omega;
     double rnorm = 0.0;
     auto refresh_rnorm = [&]() -> int32_t {
         if (h->loss != CDH_SQRT) return CDH_OK;
@@ -679,27 +729,6 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     auto settled = [&](int64_t k) {
         return h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0 && std::fabs(c.g[(size_t)k]) <= cert(k);
     };
-    if (!want.empty()) {
-        // fill the last batch of 32 with the inactive coordinates nearest their threshold: the likeliest to
-        // enter the support next (on a lambda path: at one of the next lambdas)
-        const size_t room = (kCrossB - want.size() % kCrossB) % kCrossB;
-        if (room > 0 && c.moved.empty()) {
-            CHK(gc_need_host_g(h));
-            CHK(refresh_rnorm());
-            std::vector<std::pair<double, int64_t>> near;
-            for (int64_t k = 0; k < h->p; ++k)
-                if (c.slot[(size_t)k] < 0 && h->x.get(k) == 0.0 && c.a[(size_t)k] > 0.0)
-                    near.emplace_back(std::fabs(c.g[(size_t)k]) / thr_of(k), k);
-            const size_t take = std::min(room, near.size());
-            std::partial_sort(near.begin(), near.begin() + (std::ptrdiff_t)take, near.end(), std::greater<std::pair<double, int64_t>>());
-            for (size_t i = 0; i < take; ++i) want.push_back(near[i].second);
-        }
-        CHK(gc_fetch(h, want));
-        if (c.mode == 0) return CDH_OK;
-    }
-    for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return fail(h, CDH_BAD_ARG, "gradient cache: a moved coordinate has no Gram column");
-    gc_fold(h);
-    if (!c.valid) return CDH_OK;      // (a device fold that failed hard leaves no gradient: the pass runs the plain way)
     CHK(refresh_rnorm());
     // 2. the whole pass on the device where it can be (g stays there); else -- and after a failed re-check -- the
     //    windowed walk below, with g on the host

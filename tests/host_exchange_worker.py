@@ -117,6 +117,31 @@ def main():
         assert "exchange" in str(e)
     cp.barrier()
     f.close()
+    # Near-equal shards on opposite sides of the default-width cut (cdh_create: B = 64 below 262 144 local rows, else 32):
+    # 524 287 rows over two ranks are 262 144 + 262 143.  Nobody sets a width here -- the handles agree on one through the
+    # exchange before their first streamed chunk; ranks with different B would issue different numbers and sizes of
+    # all-reduces per pass (a hang, or wrong sums).
+    if cp.world == 2:
+        n3, p3 = 524287, 80
+        rng3 = np.random.default_rng(29)
+        X3 = np.asfortranarray(rng3.standard_normal((n3, p3)))
+        y3 = X3[:, :6] @ (2 * rng3.standard_normal(6)) + rng3.standard_normal(n3)
+        r3, nl3 = sharded.shard_rows(n3, cp.rank, cp.world)
+        assert nl3 == (262144 if cp.rank == 0 else 262143)
+        f = cd.CDLeastSquaresLoss(y3[r3:r3 + nl3], X3[r3:r3 + nl3], device=0, n_total=n3, row_offset=r3)
+        sharded.connect_host(f, cp)
+        f.set_gradient_cache(0)
+        fo = O.CDLeastSquaresLoss(y3, X3)
+        x, xo = cd.SparseIterate(p3), O.SparseIterate(p3)
+        before = f.exchange_stats()["host_calls"]
+        cd.coordinateDescent_(x, f, cd.ProxL1(0.05), cd.CDOptions(**o))
+        O.coordinateDescent_(xo, fo, O.ProxL1(0.05), O.CDOptions(**o))
+        assert float(np.max(np.abs(x.dense() - xo.dense()))) < 1e-10
+        assert same_on_all_ranks(x.dense())
+        calls = float(f.exchange_stats()["host_calls"] - before)
+        assert same_on_all_ranks(np.array([calls])), "ranks issued different numbers of all-reduces"
+        cp.barrier()
+        f.close()
     if cp.rank == 0:
         print("HOSTX_OK")
     cp.shutdown()
