@@ -324,6 +324,18 @@ class _HipLoss(CoordinateDifferentiableFunction):
         return dict(zip(("passes", "settled_visits", "exact_visits", "reference_passes", "gram_batches", "gram_columns",
                          "covariance_visits", "residual_catchups", "rollbacks", "device_passes"), [int(v) for v in out]))
 
+    def set_device_loop(self, on=True):
+        """The pass loop of a cache-served solve on the device (cdh_set_device_loop; on by default)."""
+        check(self._L.cdh_set_device_loop(self._h, int(bool(on))), self._h)
+
+    def device_loop_stats(self):
+        out = (C.c_int64 * 12)()
+        check(self._L.cdh_device_loop_stats(self._h, out), self._h)
+        d = dict(zip(("launches", "passes", "folds", "exact_rechecks"), [int(x) for x in out[:4]]))
+        d["phase_us"] = dict(zip(("list", "scan", "exact_g", "visits", "recheck", "accept", "bookkeeping", "dropzeros_rest"),
+                                 [int(x) / 100.0 for x in out[4:]]))
+        return d
+
     def set_use_graph(self, on=True):
         check(self._L.cdh_set_use_graph(self._h, int(bool(on))), self._h)
 

@@ -83,6 +83,7 @@ constexpr int kNcclSum = 0;
 // only.  Same iterates as visiting one by one: a coordinate is skipped only when the exact path would have
 // left it at zero (1e-9 relative margin, as for the dots-only screens), everything else is visited by the
 // same kernels.  fp64 storage, no observation weights.
+#include "cov_solve_types.hpp"   // CovSolveCtl, CovSolveBufs (the kernel and its host side: cov_solve.hpp, below)
 struct GradCache {
     int mode = 1;                   // 0 off, 1 rent-or-buy, 2 from the first full pass (both only where the host-side
                                     // fold is cheaper than reading X), 3 from the first full pass, unconditionally
@@ -135,6 +136,22 @@ struct GradCache {
     int64_t n_drift = 0;
     int64_t n_validate = 0, n_batches = 0, n_columns = 0, n_certified = 0, n_exact = 0, n_passes = 0, n_cov = 0,
             n_reconcile = 0;
+    // the device-resident pass loop (cov_solve.hpp): its scratch, the pinned block it reads from and writes into, the bound's M_k
+    bool cs_enabled = true;          // env CDH_COV_SOLVE (default 1)
+    bool cs_shuffle_ok = true, cs_stalled = false;
+    size_t cs_lds_budget = 0;
+    char *cs_dev = nullptr, *cs_pin = nullptr, *cs_pin_dev = nullptr;
+    CovSolveBufs cs_bufs{};
+    CovSolveCtl* cs_ctl = nullptr;
+    int32_t *cs_in_sup = nullptr, *cs_out_sup_idx = nullptr, *cs_out_moved_idx = nullptr, *cs_out_list = nullptr;
+    double *cs_out_sup_val = nullptr, *cs_out_moved_val = nullptr, *d_colmax = nullptr;
+    int64_t colmax_slots = 0;        // columns of the device store already folded into d_colmax
+    bool slot_dev_ok = false;        // d_slot mirrors `slot`
+    std::vector<double> cs_old;      // scratch: the iterate's values before a launch, by coordinate (zero between launches)
+    int prep_state = 0;              // gc_prepare_full has run for the pass about to be walked: 1 go, 2 no-go (0: not yet)
+    double prep_cert_abs = 0.0;
+    int64_t n_cs_launches = 0, n_cs_passes = 0, n_cs_folds = 0, n_cs_exact = 0;
+    int64_t cs_ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs_cycles = 0, cs_ticks_total = 0;
 };
 
 // The one-launch solve of problems that fit on chip (small_solve.hpp): the full Gram matrix of the resident X, the
@@ -227,6 +244,16 @@ struct cdh_handle_s {
     // caller loads another iterate without initialize! (cdh_set_iterate leaves r alone, as the reference's x[k] = ... does).
     bool r_lazy = false;
     cdh::SupportList x_lazy;
+    // What is known about the residual BUFFER: `r_pristine` -- it is bit for bit what initialize! makes of the iterate
+    // x_pristine (k_init_resid is deterministic) and nothing has written it since: another initialize! of that very iterate
+    // changes nothing and is skipped (lasso.jl:250-252 calls initialize! at every lambda; utils.jl / lasso.jl front-ends call
+    // it right after _findLambdaMax).  `dots_valid` -- dots_stash holds (X_k'W r, X_k'W X_k) for all k of the residual the
+    // handle stands for as of now (taken by _findLambdaMax / cdh_xt_r): the gradient cache's reference pass adopts them
+    // instead of reading X again.  Everything that writes r, queues updates for it, or changes X, y, W clears both.
+    bool r_pristine = false, dots_valid = false, dots_w = false;
+    cdh::SupportList x_pristine;
+    std::vector<double> dots_stash;
+    int64_t n_rebuild_skipped = 0, n_dots_adopted = 0;
     int64_t r_roundings = 0;      // launches that have rewritten r (each rounds it to the storage type once) since it was last rebuilt
     bool chunk_dup = false;       // the current chunk's visit list repeats a coordinate
     std::vector<int32_t> stamp;   // duplicate detection scratch, size p
@@ -336,6 +363,9 @@ inline bool sharded(const cdh_handle_s* h) {
     return h->comm != nullptr || h->p2p_on || h->p2p_dead || h->lost_exchange || h->host_fn != nullptr;
 }
 
+// r (the buffer, or the residual it stands for) is about to change, or X / y / W are: what was known about it is void
+inline void touch_r(cdh_handle_s* h) { h->r_pristine = false; h->dots_valid = false; }
+
 // A shard that has lost its exchange refuses to sweep at all -- also where a pass could be served from sums exchanged
 // earlier (the gradient cache): the ranks of one problem must fail together, not one by one as they come to need an exchange.
 int32_t exchange_alive(cdh_handle h) {
@@ -429,6 +459,7 @@ int32_t sync_r(cdh_handle h) {
         return rebuild_residual_from(h, h->x_lazy, false);
     }
     if (h->r_pending_list.empty()) return CDH_OK;
+    h->r_pristine = false;            // (the residual the handle stands for does not change: dots taken of it stay good)
     std::vector<int64_t>& L = h->r_pending_list;
     for (size_t o = 0; o < L.size(); o += 64) {
         const int cnt = (int)std::min<size_t>(64, L.size() - o);
@@ -550,6 +581,8 @@ void gc_invalidate(cdh_handle h, bool columns) {
         c.a_dev_ok = false;
         c.G.clear(); c.G.shrink_to_fit();
         std::fill(c.slot.begin(), c.slot.end(), -1);
+        c.slot_dev_ok = false;           // d_slot still names the old columns until the next upload (cov_solve.hpp reads it)
+        c.colmax_slots = 0;
         c.dev_slots = 0;                 // the device store is refilled from slot 0 (its memory is kept)
         c.full_seen = 0;
     }
@@ -594,7 +627,30 @@ void gc_note_moves(cdh_handle h, const int64_t* idx0, int m) {
 }
 
 // ---- initialize!: upload support, r = y - X beta ------------------------------------
+inline bool same_iterate(const cdh::SupportList& a, const cdh::SupportList& b) {
+    if (a.size() != b.size() || a.nnz() != b.nnz()) return false;
+    for (int64_t s = 0; s < a.nnz(); ++s) if (a.coord(s) != b.coord(s) || !(a.slot_value(s) == b.slot_value(s))) return false;
+    return true;
+}
 int32_t rebuild_residual_from(cdh_handle h, const cdh::SupportList& x, bool upload_beta) {
+    if (h->r_pristine && !h->r_lazy && h->r_pending_list.empty() && same_iterate(x, h->x_pristine)) {
+        // the buffer already holds exactly what this rebuild would write
+        if (upload_beta) {
+            if (x.nnz() == 0) HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
+            else {
+                std::vector<double> dense((size_t)h->p, 0.0);
+                for (int64_t s = 0; s < x.nnz(); ++s) dense[(size_t)x.coord(s)] = x.slot_value(s);
+                HIPCHK(h, hipMemcpyAsync(h->beta, dense.data(), sizeof(double) * h->p, hipMemcpyHostToDevice, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+            }
+        }
+        h->r_roundings = 1;
+        h->r_consistent = true;
+        h->n_rebuild_skipped += 1;
+        gc_after_rebuild(h, x);
+        return CDH_OK;
+    }
+    touch_r(h);
     drop_r_pending(h);
     h->r_lazy = false;
     h->r_roundings = 1;               // r = y - X beta, summed in fp64 and rounded once
@@ -603,6 +659,7 @@ int32_t rebuild_residual_from(cdh_handle h, const cdh::SupportList& x, bool uplo
         if (upload_beta) HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->r, h->y, (size_t)h->ld * h->esz, hipMemcpyDeviceToDevice, h->stream));
         h->r_consistent = true;
+        h->r_pristine = true; h->x_pristine = x;
         gc_after_rebuild(h, x);
         return CDH_OK;
     }
@@ -627,6 +684,7 @@ int32_t rebuild_residual_from(cdh_handle h, const cdh::SupportList& x, bool uplo
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors above go out of scope
     h->r_consistent = true;
+    h->r_pristine = true; h->x_pristine = x;
     gc_after_rebuild(h, x);
     return CDH_OK;
 }
@@ -808,6 +866,7 @@ int32_t agree_default_width(cdh_handle h) {
 int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     CHK(agree_default_width(h));
     CHK(sync_r(h));   // the streaming kernels read and write r
+    touch_r(h);
     if (h->p2p_epoch >= kEpochSoftWrap) h->p2p_epoch = (h->p2p_epoch & 1u) ? 1u : 2u;   // slot parity keeps alternating
     std::memcpy(h->h_idx, idx0, sizeof(int64_t) * (size_t)m);
     note_duplicates(h, idx0, m);
@@ -913,8 +972,10 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
     return CDH_OK;
 }
 
+constexpr int kScreenMinPass = 16;   // screens / the cache: passes over fewer coordinates than that are a block or two anyway
 #include "grad_cache.hpp"   // gc_size, gc_validate, gc_fetch, gc_fold, gc_full_pass
 #include "small_solve.hpp"  // small_applicable, small_prepare, small_solve
+#include "cov_solve.hpp"    // k_cov_solve, cov_solve: the pass loop of a cache-served solve on the device
 
 // _cdPass! (coordinate_descent.jl:94-110)
 // Screening of a FULL pass (exact, no reference counterpart).  A visit of a coordinate with
@@ -928,7 +989,7 @@ int32_t run_chunk(cdh_handle h, const int64_t* idx0, int m, double* maxH) {
 // repeated hits), so a pass in which everything moves pays for a handful of screens only; a screen
 // that settles all of its columns doubles the next one (64 -> 1024 columns: one host round trip per
 // screen, so long quiet stretches run at the plain streaming rate of k_col_dots).
-constexpr int kScreen = 64, kScreenMax = 1024, kScreenMinPass = 16;   // (passes over fewer coordinates than that: a block or two anyway)
+constexpr int kScreen = 64, kScreenMax = 1024;
 
 int32_t screened_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH) {
     {   // from the gradient cache when it is engaged: no read of X for the settled visits at all
@@ -1014,16 +1075,26 @@ int32_t solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched, cd
     bool prev_converged = false, converged = true;
     std::vector<int64_t> visit;
     st->converged = 0;
-    for (int64_t iter = 0; iter < o->maxIter; ++iter) {
+    for (int64_t iter = 0; iter < o->maxIter;) {
+        // while the gradient cache can serve the passes, the loop itself runs on the device (cov_solve.hpp): one host round
+        // trip per solve; what comes back is where the state machine stands
+        {
+            int outcome = kCsNotNow;
+            CHK(cov_solve(h, o, sched, st, &prev_converged, &converged, &iter, &outcome));
+            if (outcome == kCsFinished) break;
+            if (outcome == kCsAgain) continue;
+        }
         const bool full = converged;
         sched.next_pass(h->x, full, visit);
         double maxH = 0.0;
         if (!visit.empty()) CHK(run_pass(h, visit.data(), (int64_t)visit.size(), &maxH, full));
         else h->x.dropzeros();
+        h->gc.prep_state = 0;
         st->passes += 1; st->visits += (int64_t)visit.size(); st->maxH = maxH;
         if (full) st->full_passes += 1;
         prev_converged = converged;
         converged = maxH < o->optTol;
+        ++iter;
         if (prev_converged && converged) { st->converged = 1; break; }
     }
     st->domain_error = h->domain_error ? 1 : 0;
@@ -1042,6 +1113,7 @@ int32_t lambda_max(cdh_handle h, double* out, std::vector<double>* dots = nullpt
         HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->dots_stash = cd; h->dots_valid = true; h->dots_w = h->loss == CDH_WLS;   // (col_dots has brought r up to date first)
     if (h->loss == CDH_SQRT) denom = std::sqrt(h->h_red[1]);
     const std::vector<double>& om = h->h_omega;
     double lmax = 0.0;
@@ -1079,6 +1151,8 @@ void free_all(cdh_handle h) {
         for (void* q : dv) if (q) (void)hipFree(q);
         if (c.h_scanbuf) (void)hipHostFree(c.h_scanbuf);
         if (c.h_pack) (void)hipHostFree(c.h_pack);
+        if (c.cs_dev) (void)hipFree(c.cs_dev);
+        if (c.cs_pin) (void)hipHostFree(c.cs_pin);
     }
     if (h->h_xchg) (void)hipHostFree(h->h_xchg);
     if (h->p2p_timeout) (void)hipHostFree(h->p2p_timeout);
@@ -1154,6 +1228,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->ks = env_int("CDH_KS", 0);
         h->gc.mode = std::max(0, std::min(3, env_int("CDH_GRADIENT_CACHE", 1)));
         h->gc.cov = env_int("CDH_GC_COV", 1) != 0;
+        h->gc.cs_enabled = env_int("CDH_COV_SOLVE", 1) != 0;
         h->small.enabled = env_int("CDH_SMALL_PATH", 1) != 0;
         if (const char* e = getenv("CDH_SMALL_MAX_BYTES")) h->small.max_bytes = std::atoll(e);
         h->small.zero_copy = env_int("CDH_SMALL_ZEROCOPY", 1) != 0;
@@ -1242,6 +1317,7 @@ int32_t cdh_set_X_cols(cdh_handle h, int64_t j0, int64_t ncols, const void* host
         CHK(sync_r(h));
     }
     h->r_consistent = false;
+    touch_r(h);
     gc_invalidate(h, true);
     h->small.G_valid = false; h->small.c_valid = false; h->small.rent_paid = 0.0;
     if (j0 < 0 || ncols < 0 || j0 + ncols > h->p || ld < h->n) return fail(h, CDH_DIM_MISMATCH, "column block outside X");
@@ -1271,6 +1347,7 @@ int32_t cdh_set_y(cdh_handle h, const void* host_y) {
     NEED_H(h);
     NEED_P(h, host_y);
     h->r_consistent = false;
+    touch_r(h);
     gc_invalidate(h, false);
     h->gc.yy_ok = false;
     h->small.c_valid = false;
@@ -1305,6 +1382,7 @@ int32_t cdh_set_obs_weights(cdh_handle h, const void* host_w) {
     NEED_H(h);
     NEED_P(h, host_w);
     h->r_consistent = false;
+    touch_r(h);
     gc_invalidate(h, true);
     h->small.G_valid = false; h->small.c_valid = false; h->small.rent_paid = 0.0;
     if (h->loss != CDH_WLS) return fail(h, CDH_BAD_ARG, "observation weights need the CDH_WLS loss");
@@ -1327,6 +1405,7 @@ int32_t cdh_set_loss(cdh_handle h, int32_t loss) {
     if (h->has_w) { h->small.G_valid = false; h->small.c_valid = false; h->small.rent_paid = 0.0; gc_invalidate(h, true); }   // X'WX is not X'X
     h->has_w = false;             // a weighted loss gets its weights from cdh_set_obs_weights
     h->r_consistent = false;
+    touch_r(h);
     gc_invalidate(h, false);
     h->domain_error = false;
     return CDH_OK;
@@ -1334,6 +1413,7 @@ int32_t cdh_set_loss(cdh_handle h, int32_t loss) {
 
 static int32_t cdh_generate_impl(cdh_handle h, uint64_t seed, int64_t s, double noise, double* out_beta_star) {
     if (s < 0 || s > h->p) return fail(h, CDH_BAD_ARG, "need 0 <= s <= p");
+    touch_r(h);
     gc_invalidate(h, true);
     h->gc.yy_ok = false;
     h->small.G_valid = false; h->small.c_valid = false; h->small.rent_paid = 0.0;
@@ -1486,6 +1566,7 @@ static int32_t cdh_pass_impl(cdh_handle h, int64_t m, const int64_t* idx1, doubl
         idx0[(size_t)i] = idx1[i] - 1;
     }
     double maxH = 0.0;
+    h->gc.prep_state = 0;
     if (m > 0) CHK(run_pass(h, idx0.data(), m, &maxH, h->screening >= 2));
     else h->x.dropzeros();
     if (out_maxH) *out_maxH = maxH;
@@ -1637,6 +1718,7 @@ static int32_t cdh_xt_r_impl(cdh_handle h, double* out_p) {
     HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * h->p, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int64_t j = 0; j < h->p; ++j) out_p[j] = cd[(size_t)(2 * j)];
+    h->dots_stash.swap(cd); h->dots_valid = true; h->dots_w = false;
     return CDH_OK;
 }
 
@@ -1784,6 +1866,21 @@ int32_t cdh_cache_stats(cdh_handle h, int64_t* out10) {
     out10[3] = c.n_validate; out10[4] = c.n_batches; out10[5] = c.n_columns;
     out10[6] = c.n_cov; out10[7] = c.n_reconcile; out10[8] = c.n_rollbacks;
     out10[9] = c.n_dev_passes;
+    return CDH_OK;
+}
+
+int32_t cdh_set_device_loop(cdh_handle h, int32_t on) {
+    NEED_H(h);
+    h->gc.cs_enabled = on != 0;
+    return CDH_OK;
+}
+
+int32_t cdh_device_loop_stats(cdh_handle h, int64_t* out12) {
+    NEED_H(h);
+    NEED_P(h, out12);
+    out12[0] = h->gc.n_cs_launches; out12[1] = h->gc.n_cs_passes; out12[2] = h->gc.n_cs_folds; out12[3] = h->gc.n_cs_exact;
+    for (int i = 0; i < 8; ++i) out12[4 + i] = h->gc.cs_ticks[i];
+    if (getenv("CDH_COV_SOLVE_CLOCK")) fprintf(stderr, "k_cov_solve: %lld cycles in %lld ticks of 10 ns: %.3f GHz\n", (long long)h->gc.cs_cycles, (long long)h->gc.cs_ticks_total, h->gc.cs_ticks_total ? (double)h->gc.cs_cycles / (double)h->gc.cs_ticks_total * 0.1 : 0.0);
     return CDH_OK;
 }
 

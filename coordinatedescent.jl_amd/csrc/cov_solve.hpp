@@ -30,70 +30,98 @@
 // coordinate (tests: the legs of tests/_legs.py, the stateful fuzz, tests/test_gpu_cov_solve.py).
 #pragma once
 
-constexpr int kCsThreads = 512;          // 8 waves: gram_scalar_body<4> holds a 64-entry Gram column per lane (128 VGPRs)
+constexpr int kCsThreads = 256;          // 4 waves, one per SIMD: gram_scalar_body<4> holds a 64-entry Gram column per lane (128 VGPRs) next to the loops' state
 constexpr int kCsWaves = kCsThreads / 64;
 constexpr int kCsNearMax = 96;           // inactive coordinates failing the bound beyond which the kernel folds and scans again
 constexpr int64_t kCsShuffleMaxP = 12288;   // the shuffle's two p-sized int arrays must fit LDS
+constexpr size_t kCsLdsBudget = (size_t)134 * 1024;   // dynamic LDS next to ~24 KB of static arrays (160 KB per CU)
+constexpr int kCsUcapMax = 124;          // tracked coordinates whose Gram block is kept in LDS (124 x 124 doubles = 120 KB)
 
-enum { kCsConverged = 0, kCsMaxIter = 1, kCsNeedColumns = 2, kCsRollback = 3, kCsBusy = 4, kCsRefresh = 5, kCsOutgrown = 6 };
-
-struct CovSolveCtl {
-    // in
-    double lambda0, n_total, optTol, cert_abs;
-    int64_t max_passes;          // passes this launch may run (maxIter - those already done)
-    int64_t cov_budget;          // covariance-form visits this launch may make before g is due to be re-read from X
-    int32_t loss, has_omega, randomize, nnz_limit /* support size beyond which the cache stands aside */;
-    int32_t busy_limit, inject_every, pad0, pad1;
-    // in / out
-    uint64_t rng;
-    double q;                    // r'r (sqrt-lasso)
-    int32_t nnz, prev_conv, conv, inject_count;
-    // out
-    int32_t status, n_list /* kCsNeedColumns / kCsBusy: coordinates that want a Gram column (out_list) */, n_moved, domain_error;
-    int64_t passes, full_passes, visits, cov_visits, settled, folds, exact_rechecks;
-    double maxH;
-};
-
-struct CovSolveBufs {
-    int64_t p;
-    double* g; const double* Gcols; const int32_t* slot; const double* a; const double* colmax; const double* omega;
-    double* beta;
-    double *gx, *bfold, *bsnap, *hs, *newval, *qs, *tv, *pendv;
-    int64_t *uk, *poff, *voff;
-    int32_t *touched, *s2i, *i2s, *list, *vb, *moved, *holes, *fills;
-    uint8_t *setflag, *inmoved;
-    const int32_t* in_sup;                   // the support in slot order (pinned host memory, read once)
-    int32_t *out_sup_idx, *out_moved_idx, *out_list;   // pinned host memory, written once at the end
-    double *out_sup_val, *out_moved_val;
-};
-
-// exclusive rank of `flag` among the block's threads (thread order), and the block's total; s_w: kCsWaves ints of LDS
-__device__ __forceinline__ int cs_block_rank(bool flag, int& total, int* s_w) {
+// Ranks inside a block, E positions per thread (thread t owns positions base + E t .. base + E t + E - 1: rank order is
+// position order).  rank[e] = exclusive rank of flag[e]; returns the block's total.  s_w: 2 * kCsWaves ints of LDS.
+template <int E>
+__device__ __forceinline__ int cs_rank(const bool (&f)[E], int (&rank)[E], int* s_w) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long mask = __ballot(flag);
-    if (lane == 0) s_w[wave] = __popcll(mask);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int mine = 0, wtot = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const unsigned long long m = __ballot(f[e]); mine += __popcll(m & below); wtot += __popcll(m); }
+    if (lane == 0) s_w[wave] = wtot;
     __syncthreads();
     int before = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < kCsWaves; ++w) { const int c = s_w[w]; tot += c; if (w < wave) before += c; }
     __syncthreads();
-    total = tot;
-    return before + __popcll(mask & ((1ull << lane) - 1ull));
+    int run = before + mine;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { rank[e] = run; run += f[e] ? 1 : 0; }
+    return tot;
 }
-__device__ __forceinline__ int cs_block_count(bool flag, int* s_w) { int t; (void)cs_block_rank(flag, t, s_w); return t; }
+// two flag sets ranked at once (one pair of barriers)
+template <int E>
+__device__ __forceinline__ void cs_rank2(const bool (&f)[E], const bool (&g)[E], int (&rf)[E], int (&rg)[E], int& totf, int& totg, int* s_w) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int mf = 0, wf = 0, mg = 0, wg = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const unsigned long long a = __ballot(f[e]), c = __ballot(g[e]);
+        mf += __popcll(a & below); wf += __popcll(a); mg += __popcll(c & below); wg += __popcll(c);
+    }
+    if (lane == 0) { s_w[wave] = wf; s_w[kCsWaves + wave] = wg; }
+    __syncthreads();
+    int bf = 0, tf = 0, bg = 0, tg = 0;
+#pragma unroll
+    for (int w = 0; w < kCsWaves; ++w) {
+        const int c = s_w[w], d = s_w[kCsWaves + w];
+        tf += c; tg += d;
+        if (w < wave) { bf += c; bg += d; }
+    }
+    __syncthreads();
+    int runf = bf + mf, rung = bg + mg;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { rf[e] = runf; runf += f[e] ? 1 : 0; rg[e] = rung; rung += g[e] ? 1 : 0; }
+    totf = tf; totg = tg;
+}
+// block-wide sum of a per-thread count
+__device__ __forceinline__ int cs_block_sum(int v, int* s_w) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) s_w[wave] = v;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < kCsWaves; ++w) tot += s_w[w];
+    __syncthreads();
+    return tot;
+}
 
-__global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovSolveBufs b) {
+constexpr int kCsE = 4;      // positions per thread and iteration of the p-sized loops: their loads are issued together,
+                             // so those loops are written WITHOUT short-circuit conditions (a conditional load is waited for on its own)
+
+// What the visits of a pass work on, indexed by position u in the pass's visit list ("tracked" coordinates): in LDS while the
+// list is at most `ucap` long, else in global scratch -- the same code through generic pointers.
+struct CsTracked {
+    int64_t *k, *voff, *iota;
+    double *beta, *om, *gx, *hs, *nv, *qs, *tv;
+    int32_t* tch;
+};
+constexpr size_t kCsTrackedBytes = 3 * 8 + 7 * 8 + 4;      // per tracked coordinate
+
+__global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovSolveBufs b, int ucap /* tracked coordinates whose Gram block fits LDS */) {
     using R = GramRec<4>;
     constexpr int B = R::B;
-    extern __shared__ int32_t s_shuffle[];       // randomize: order[p], draw[p]
+    constexpr int E = kCsE;
+    extern __shared__ double s_dynamic[];        // [G_UU: ucap x ucap doubles][tracked arrays: 84 ucap bytes][randomize: order[p], draw[p] int32]
     __shared__ double s_rec[R::N];
-    __shared__ int64_t s_k[B], s_off[B], s_moff[B];
+    __shared__ int s_mu[B];
     __shared__ double s_h[B];
     __shared__ Ctrl s_ctrl;
-    __shared__ int s_w[kCsWaves];
-    __shared__ int s_nmove, s_bad, s_nan;
+    __shared__ int s_w[2 * kCsWaves];
+    __shared__ int s_nmove, s_bad, s_nan, s_same;
     __shared__ double s_tvrun;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int64_t p = b.p;
     const int loss = ctl->loss, has_omega = ctl->has_omega, randomize = ctl->randomize;
     const bool sqrt_loss = loss == 1;
@@ -102,12 +130,30 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     const int nnz_limit = ctl->nnz_limit, busy_limit = ctl->busy_limit, inject_every = ctl->inject_every;
     uint64_t rng = ctl->rng;
     double q = ctl->q;
+    // 100 MHz ticks per phase (thread 0's view): list, scan, exact gradients, visits, re-check, accept, bookkeeping, dropzeros!
+    uint64_t tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tmark = __builtin_amdgcn_s_memrealtime();
+    const uint64_t cyc0 = __builtin_amdgcn_s_memtime(), tick0 = tmark;
+    auto lap = [&](int ph) { const uint64_t now = __builtin_amdgcn_s_memrealtime(); tph[ph] += now - tmark; tmark = now; };
     int nnz = ctl->nnz, inject_count = ctl->inject_count;
     bool prev_conv = ctl->prev_conv != 0, conv = ctl->conv != 0;
-    int32_t* s_order = s_shuffle;
-    int32_t* s_draw = s_shuffle + p;
+    double* s_G = s_dynamic;
+    CsTracked lt;                                 // the LDS copy of the tracked arrays
+    {
+        double* d = s_dynamic + (size_t)ucap * ucap;
+        lt.k = reinterpret_cast<int64_t*>(d); d += ucap;
+        lt.voff = reinterpret_cast<int64_t*>(d); d += ucap;
+        lt.iota = reinterpret_cast<int64_t*>(d); d += ucap;
+        lt.beta = d; d += ucap; lt.om = d; d += ucap; lt.gx = d; d += ucap; lt.hs = d; d += ucap;
+        lt.nv = d; d += ucap; lt.qs = d; d += ucap; lt.tv = d; d += ucap;
+        lt.tch = reinterpret_cast<int32_t*>(d);
+    }
+    int32_t* s_order = lt.tch + ((ucap + 1) & ~1);
+    int32_t* s_draw = s_order + p;
+    const CsTracked gt{b.uk, b.voff, b.iota, b.ubeta, b.uom, b.ugx, b.hs, b.newval, b.qs, b.tv, b.touched};   // ... and the global one
 
-    for (int64_t k = tid; k < p; k += kCsThreads) { b.i2s[k] = 0; b.bfold[k] = b.beta[k]; b.inmoved[k] = 0; }
+    for (int64_t k = tid; k < p; k += kCsThreads) { b.i2s[k] = 0; b.bfold[k] = b.beta[k]; b.inmoved[k] = 0; b.gxp[k] = -1; b.iota[k] = k; }
+    for (int u = tid; u < ucap; u += kCsThreads) lt.iota[u] = u;
     if (tid == 0) {
         s_ctrl.lambda0 = lambda0; s_ctrl.n_total = n_total; s_ctrl.maxH = 0.0; s_ctrl.loss = loss; s_ctrl.has_omega = has_omega;
         s_ctrl.domain_error = 0; s_ctrl.pad = 0; s_ctrl.q_carry = q; s_ctrl.cert_abs = cert_abs;
@@ -117,34 +163,52 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     __syncthreads();
 
     int nmoved = 0, status = kCsMaxIter, n_list = 0, dom_any = 0;
+    int pass_id = 1;             // gx_k is current iff gxp[k] == pass_id - 1: k was tracked in the pass just before
+    int cnt_prev = -1;           // the tracked list G_UU in LDS was filled for (b.uprev[0 .. cnt_prev))
     double TV0 = 0.0, lastH = 0.0;
-    int64_t passes = 0, full_passes = 0, visits = 0, cov_visits = 0, settled_total = 0, folds = 0, exact_rechecks = 0;
+    int64_t passes = 0, full_passes = 0, visits = 0, cov_visits = 0, cov_visits_full = 0, settled_total = 0, folds = 0, exact_rechecks = 0;
 
-    // g <- g - sum_m pend_m G_m over all p; nothing is pending afterwards
-    auto fold = [&]() {
+    auto stage_pending = [&]() {       // pend_m and the column offset of every coordinate moved since the fold
         for (int m = tid; m < nmoved; m += kCsThreads) {
             const int km = b.moved[m];
             b.pendv[m] = b.beta[km] - b.bfold[km];
             b.poff[m] = (int64_t)b.slot[km] * p;
         }
         __syncthreads();
-        for (int64_t k = tid; k < p; k += kCsThreads) {
-            double acc = b.g[k];
-            for (int m = 0; m < nmoved; ++m) acc = fma(-b.pendv[m], b.Gcols[b.poff[m] + k], acc);
-            b.g[k] = acc;
+    };
+    // g_k - sum_m pend_m G_mk: 8 gathers in flight
+    auto exact_g = [&](int64_t k) {
+        double acc = b.g[k];
+        int m = 0;
+        for (; m + 8 <= nmoved; m += 8) {
+            double gv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) gv[t] = b.Gcols[b.poff[m + t] + k];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc = fma(-b.pendv[m + t], gv[t], acc);
         }
+        for (; m < nmoved; ++m) acc = fma(-b.pendv[m], b.Gcols[b.poff[m] + k], acc);
+        return acc;
+    };
+    // g <- g - sum_m pend_m G_m over all p; nothing is pending afterwards
+    auto fold = [&]() {
+        stage_pending();
+        for (int64_t k = tid; k < p; k += kCsThreads) b.g[k] = exact_g(k);
         for (int m = tid; m < nmoved; m += kCsThreads) { const int km = b.moved[m]; b.bfold[km] = b.beta[km]; b.inmoved[km] = 0; }
         __syncthreads();
         nmoved = 0; TV0 = 0.0; folds += 1;
     };
 
     for (;;) {
+        lap(7);
         if (passes >= max_passes) { status = kCsMaxIter; break; }
         if (nnz > nnz_limit) { status = kCsOutgrown; break; }
         if (cov_visits > cov_budget) { status = kCsRefresh; break; }
         const bool full = conv;
         const uint64_t rng_before = rng;
         const int L = full ? (int)p : nnz;
+        const int Lm1 = L > 0 ? L - 1 : 0;
+        const bool direct = full && !randomize;      // an ordered full pass visits k = i: no list
         // ---- reset!(it, full) + collect(it) (atom_iterator.jl:34-37, 53-64; the splitmix64 substitute of sparse_iterate.hpp) ----
         if (randomize) {
             for (int i = tid; i < L; i += kCsThreads) {
@@ -160,192 +224,278 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 for (int i = 0; i + 1 < L; ++i) { const int j = s_draw[i]; const int t = s_order[i]; s_order[i] = s_order[j]; s_order[j] = t; }
             __syncthreads();
             for (int i = tid; i < L; i += kCsThreads) b.list[i] = full ? s_order[i] : b.s2i[s_order[i]];
-        } else {
-            for (int i = tid; i < L; i += kCsThreads) b.list[i] = full ? i : b.s2i[i];
+        } else if (!full) {
+            for (int i = tid; i < L; i += kCsThreads) b.list[i] = b.s2i[i];
         }
         __syncthreads();
+        lap(0);
 
-        // ---- the scan: which positions are visited (cdh: "unsettled"), in visit order ----
+        // ---- the scan: which positions are visited ("unsettled"), in visit order ----
         int cnt = 0, nocol = 0, nzero = 0, nsupp = 0;
         for (int attempt = 0;; ++attempt) {
-            cnt = 0; nocol = 0; nzero = 0; nsupp = 0;
+            cnt = 0; nocol = 0;
+            int nz_mine = 0, ns_mine = 0;
             const double thr_base = lambda0 * (sqrt_loss ? sqrt(q) : n_total);
-            for (int i0 = 0; i0 < L; i0 += kCsThreads) {
-                const int i = i0 + tid;
-                const bool valid = i < L;
-                const int k = valid ? b.list[i] : 0;
-                const double gk = b.g[k], bk = b.beta[k];
-                bool st = false;
-                if (valid && full && bk == 0.0) {
-                    const double ak = b.a[k], om = has_omega ? b.omega[k] : 1.0;
-                    st = ak > 0.0 && fabs(gk) + b.colmax[k] * TV0 <= thr_base * om * (1.0 - 1e-9) - cert_abs * sqrt(ak);
+            for (int i0 = 0; i0 < L; i0 += kCsThreads * E) {
+                int k[E], sl[E];
+                bool valid[E], uns[E], nc[E], st[E];
+                double gk[E], bk[E], ak[E], om[E], mk[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = i0 + tid * E + e;
+                    valid[e] = i < L;
+                    const int ic = min(i, Lm1);
+                    k[e] = direct ? ic : b.list[ic];
                 }
-                const bool uns = valid && !st;
-                const bool nc = uns && b.slot[k] < 0;
-                int tot_u, tot_c;
-                const int j = cnt + cs_block_rank(uns, tot_u, s_w);
-                const int jl = nocol + cs_block_rank(nc, tot_c, s_w);
-                if (valid) {
-                    b.vb[k] = j;                      // visited: its index in the visit list; settled: visits before its turn
-                    if (full) b.setflag[k] = st ? 1 : 0;
-                    if (uns) b.uk[j] = k;
-                    if (nc) b.out_list[jl] = k;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {                        // every load unconditional (clamped index): all in flight together
+                    gk[e] = b.g[k[e]]; bk[e] = b.beta[k[e]]; sl[e] = b.slot[k[e]];
+                    ak[e] = b.a[k[e]]; mk[e] = b.colmax[k[e]]; om[e] = has_omega ? b.omega[k[e]] : 1.0;
                 }
-                nzero += cs_block_count(st && gk == 0.0, s_w);
-                nsupp += cs_block_count(uns && bk != 0.0, s_w);
-                cnt += tot_u; nocol += tot_c;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    st[e] = valid[e] & full & (bk[e] == 0.0) & (ak[e] > 0.0) &
+                            (fabs(gk[e]) + mk[e] * TV0 <= thr_base * om[e] * (1.0 - 1e-9) - cert_abs * sqrt(ak[e]));
+                    uns[e] = valid[e] & !st[e];
+                    nc[e] = uns[e] & (sl[e] < 0);
+                    nz_mine += (st[e] & (gk[e] == 0.0)) ? 1 : 0;
+                    ns_mine += (uns[e] & (bk[e] != 0.0)) ? 1 : 0;
+                }
+                int ru[E], rc[E], tu, tc;
+                cs_rank2<E>(uns, nc, ru, rc, tu, tc, s_w);
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (valid[e]) {
+                        b.vb[k[e]] = cnt + ru[e];          // visited: its index in the visit list; settled: visits before its turn
+                        if (full) b.setflag[k[e]] = st[e] ? 1 : 0;
+                        if (uns[e]) b.uk[cnt + ru[e]] = k[e];
+                        if (nc[e]) b.out_list[nocol + rc[e]] = k[e];
+                    }
+                cnt += tu; nocol += tc;
             }
-            // many inactive coordinates fail the bound only because it has grown loose: fold and look again
-            if (full && attempt == 0 && nmoved > 0 && cnt - nsupp > kCsNearMax) { fold(); continue; }
+            nzero = cs_block_sum(nz_mine, s_w);
+            nsupp = cs_block_sum(ns_mine, s_w);
+            // many inactive coordinates fail the bound only because it has grown loose -- or one without a Gram column does,
+            // which would send the host for a pass over X: fold (exact g for everybody) and look again
+            if (attempt == 0 && nmoved > 0 && ((full && cnt - nsupp > kCsNearMax) || nocol > 0)) { fold(); pass_id += 2; continue; }
             break;
         }
         if (nocol > 0) {                 // coordinates about to be visited without a Gram column: the host fetches them
             status = nocol > busy_limit ? kCsBusy : kCsNeedColumns; n_list = nocol; rng = rng_before;
             break;
         }
+        lap(1);
 
-        // ---- the exact gradient of the visited coordinates: gx = g - sum_m pend_m G_m; beta as it stands (for an undo) ----
-        for (int m = tid; m < nmoved; m += kCsThreads) {
-            const int km = b.moved[m];
-            b.pendv[m] = b.beta[km] - b.bfold[km];
-            b.poff[m] = (int64_t)b.slot[km] * p;
-        }
+        // ---- the visited ("tracked") coordinates: beta, omega, their exact gradient (carried from the pass before where it was
+        // kept current there, else g - sum_m pend_m G_m), their Gram block ----
+        stage_pending();
+        const bool in_lds = cnt <= ucap;
+        const CsTracked T = in_lds ? lt : gt;
+        if (tid == 0) s_same = (in_lds && cnt == cnt_prev) ? 1 : 0;
         __syncthreads();
         for (int u = tid; u < cnt; u += kCsThreads) {
             const int64_t k = b.uk[u];
-            double acc = b.g[k];
-            for (int m = 0; m < nmoved; ++m) acc = fma(-b.pendv[m], b.Gcols[b.poff[m] + k], acc);
-            b.gx[k] = acc;
-            b.bsnap[u] = b.beta[k];
-            b.voff[u] = (int64_t)b.slot[k] * p;
+            const int gp = b.gxp[k];
+            const double bk = b.beta[k], gxk = b.gx[k], omk = has_omega ? b.omega[k] : 1.0;
+            const int64_t vo = (int64_t)b.slot[k] * p, kprev = b.uprev[u];
+            T.k[u] = k; T.voff[u] = vo; T.beta[u] = bk; T.om[u] = omk;
+            T.gx[u] = (gp == pass_id - 1) ? gxk : exact_g(k);
+            if (kprev != k) s_same = 0;
         }
         if (tid == 0) { s_ctrl.maxH = 0.0; s_ctrl.domain_error = 0; s_ctrl.q_carry = q; s_bad = 0; s_nan = 0; s_tvrun = 0.0; }
         const double q_start = q;
         __syncthreads();
+        if (in_lds && !s_same) {         // G_UU[i][j] = X_ki' X_kj for the tracked coordinates (symmetric; row i contiguous)
+            for (int e = tid; e < cnt * cnt; e += kCsThreads) { const int i = e / cnt, j = e - i * cnt; s_G[e] = b.Gcols[T.voff[j] + T.k[i]]; }
+            for (int u = tid; u < cnt; u += kCsThreads) b.uprev[u] = T.k[u];
+            cnt_prev = cnt;
+        } else if (!in_lds) {
+            cnt_prev = -1;
+        }
+        __syncthreads();
+        lap(2);
 
-        // ---- _cdPass! over the visit list, 64 visits at a time: k_cov_block's gather, gram_scalar_body's B sequential updates ----
+        // ---- _cdPass! over the visit list, 64 visits at a time: k_cov_block's gather, gram_scalar_body's B sequential updates
+        // (on the tracked arrays: `beta` and `omega` indexed by position, the identity as the block's coordinate list) ----
         for (int j0 = 0; j0 < cnt; j0 += B) {
             const int nb = min(B, cnt - j0);
-            if (tid < B) { const int i = tid < nb ? tid : 0; s_k[tid] = b.uk[j0 + i]; s_off[tid] = b.voff[j0 + i]; }
-            __syncthreads();
             for (int e = tid; e < B * B; e += kCsThreads) {
                 const int sI = e / B, j = e % B;
-                if (sI <= j && j < nb) s_rec[R::g(sI, j)] = b.Gcols[s_off[j] + s_k[sI]];
+                if (sI <= j && j < nb) s_rec[R::g(sI, j)] = in_lds ? s_G[(j0 + sI) * cnt + j0 + j] : b.Gcols[T.voff[j0 + j] + T.k[j0 + sI]];
             }
-            if (tid < B) s_rec[R::OFF_C + tid] = (tid < nb) ? b.gx[s_k[tid]] : 0.0;
+            if (tid < B) s_rec[R::OFF_C + tid] = (tid < nb) ? T.gx[j0 + tid] : 0.0;
             if (tid == 0) s_rec[R::OFF_Q] = s_ctrl.q_carry;
             __syncthreads();
             if (tid < 64) {
-                gram_scalar_body<4>(s_rec, nb, 0, &s_ctrl, b.beta, b.omega, b.uk, b.hs, b.newval, b.touched, j0, b.qs, tid);
+                gram_scalar_body<4>(s_rec, nb, 0, &s_ctrl, T.beta, T.om, T.iota, T.hs, T.nv, T.tch, j0, T.qs, tid);
                 // the block's moves, compacted (k_cov_gupdate's prologue), and the total variation after each visit
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const double hv = tid < nb ? b.hs[j0 + tid] : 0.0;
-                const bool nz = hv != 0.0;                       // (a NaN h counts as a move: it propagates, as in the reference)
+                const double hv = tid < nb ? T.hs[j0 + tid] : 0.0;
+                const bool nz = hv != 0.0;                       // (a NaN h counts as a move: the pass is then undone)
                 const unsigned long long mask = __ballot(nz);
-                if (nz) { const int at = __popcll(mask & ((1ull << tid) - 1ull)); s_h[at] = hv; s_moff[at] = s_off[tid]; }
+                if (nz) { const int at = __popcll(mask & ((1ull << tid) - 1ull)); s_h[at] = hv; s_mu[at] = j0 + tid; }
                 if (__ballot(hv != hv)) { if (tid == 0) s_nan = 1; }
                 double run = (hv == hv) ? fabs(hv) : 0.0;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(run, off, 64); if (tid >= off) run += o; }
                 const double base = s_tvrun;
-                if (tid < nb) b.tv[j0 + tid] = base + run;
+                if (tid < nb) T.tv[j0 + tid] = base + run;
                 if (tid == 0) s_nmove = __popcll(mask);
                 const double last = __shfl(run, 63, 64);
                 if (tid == 0) s_tvrun = base + last;
             }
             __syncthreads();
             const int nmove = s_nmove;
-            if (nmove > 0)                                       // the visits still to come in this pass see the block's moves
-                for (int u = j0 + nb + tid; u < cnt; u += kCsThreads) {
-                    const int64_t k = b.uk[u];
-                    double acc = b.gx[k];
-                    for (int i = 0; i < nmove; ++i) acc = fma(-s_h[i], b.Gcols[s_moff[i] + k], acc);
-                    b.gx[k] = acc;
+            if (nmove > 0)               // every tracked coordinate sees the block's moves (the block's own members too: gx stays current)
+                for (int u = tid; u < cnt; u += kCsThreads) {
+                    double acc = T.gx[u];
+                    if (in_lds) { for (int i = 0; i < nmove; ++i) acc = fma(-s_h[i], s_G[s_mu[i] * cnt + u], acc); }
+                    else { const int64_t k = T.k[u]; for (int i = 0; i < nmove; ++i) acc = fma(-s_h[i], b.Gcols[T.voff[s_mu[i]] + k], acc); }
+                    T.gx[u] = acc;
                 }
             __syncthreads();
         }
+        // what the p-sized loops below read by position: in global memory
+        if (in_lds)
+            for (int u = tid; u < cnt; u += kCsThreads) {
+                b.hs[u] = T.hs[u]; b.newval[u] = T.nv[u]; b.touched[u] = T.tch[u]; b.tv[u] = T.tv[u]; b.voff[u] = T.voff[u];
+                if (sqrt_loss) b.qs[u] = T.qs[u];
+            }
+        __syncthreads();
+        lap(3);
         const double tv_pass = s_tvrun, q_end = s_ctrl.q_carry;
         if (s_ctrl.domain_error) dom_any = 1;
 
         // ---- the settled positions, re-checked with the bound as it stood at their turn; exactly where the bound fails ----
         if (full && cnt < L && (tv_pass > 0.0 || TV0 > 0.0)) {
             int nexact = 0;
-            for (int64_t k = tid; k < p; k += kCsThreads) {
-                if (!b.setflag[k]) continue;
-                const int vbk = b.vb[k];
-                const double tvk = TV0 + (vbk > 0 ? b.tv[vbk - 1] : 0.0);
-                const double qk = sqrt_loss ? (vbk > 0 ? b.qs[vbk - 1] : q_start) : 0.0;
-                const double ak = b.a[k], om = has_omega ? b.omega[k] : 1.0, gk = b.g[k];
-                const double cert = lambda0 * (sqrt_loss ? sqrt(qk) : n_total) * om * (1.0 - 1e-9) - cert_abs * sqrt(ak);
-                if (fabs(gk) + b.colmax[k] * tvk <= cert) continue;
-                double acc = gk;                                  // the exact gradient when its turn came
-                for (int m = 0; m < nmoved; ++m) acc = fma(-b.pendv[m], b.Gcols[b.poff[m] + k], acc);
-                for (int i = 0; i < vbk; ++i) { const double hv = b.hs[i]; if (hv != 0.0) acc = fma(-hv, b.Gcols[b.voff[i] + k], acc); }
-                nexact += 1;
-                if (!(fabs(acc) <= cert)) s_bad = 1;
+            const int cm1 = cnt > 0 ? cnt - 1 : 0;
+            for (int64_t k0 = 0; k0 < p; k0 += kCsThreads * E) {
+                int64_t k[E];
+                bool chk[E];
+                int vbk[E], sf[E];
+                double gk[E], ak[E], om[E], mk[E], tvb[E], qsb[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const int64_t kk = k0 + tid + (int64_t)e * kCsThreads; chk[e] = kk < p; k[e] = kk < p ? kk : p - 1; }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    sf[e] = b.setflag[k[e]]; vbk[e] = b.vb[k[e]]; gk[e] = b.g[k[e]]; ak[e] = b.a[k[e]]; mk[e] = b.colmax[k[e]];
+                    om[e] = has_omega ? b.omega[k[e]] : 1.0;
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int at = min(max(vbk[e] - 1, 0), cm1);
+                    tvb[e] = b.tv[at]; qsb[e] = sqrt_loss ? b.qs[at] : 0.0;
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const double tvk = TV0 + (vbk[e] > 0 ? tvb[e] : 0.0);
+                    const double qk = vbk[e] > 0 ? qsb[e] : q_start;
+                    const double cert = lambda0 * (sqrt_loss ? sqrt(qk) : n_total) * om[e] * (1.0 - 1e-9) - cert_abs * sqrt(ak[e]);
+                    const bool fails = chk[e] & (sf[e] != 0) & !(fabs(gk[e]) + mk[e] * tvk <= cert);
+                    if (fails) {                                  // (rare) the exact gradient when its turn came
+                        double acc = exact_g(k[e]);
+                        for (int i = 0; i < vbk[e]; ++i) { const double hv = b.hs[i]; if (hv != 0.0) acc = fma(-hv, b.Gcols[b.voff[i] + k[e]], acc); }
+                        nexact += 1;
+                        if (!(fabs(acc) <= cert)) s_bad = 1;
+                    }
+                }
             }
-            exact_rechecks += nexact;                             // (this thread's; summed below)
+            exact_rechecks += nexact;                             // (this thread's; summed at the end)
         }
         __syncthreads();
         bool undo = s_bad != 0 || s_nan != 0 || (nzero > 0 && (TV0 > 0.0 || tv_pass > 0.0));
         if (full && cnt > 0 && inject_every > 0) { inject_count += 1; if (inject_count % inject_every == 0) undo = true; }
-        if (undo) {                       // the pass never happened: the host walks it the careful way
-            for (int u = tid; u < cnt; u += kCsThreads) b.beta[b.uk[u]] = b.bsnap[u];
+        if (undo) {                       // the pass never happened (beta itself was not touched): the host walks it the careful way
             status = kCsRollback; rng = rng_before;
-            __syncthreads();
             break;
         }
+        lap(4);
 
-        // ---- accepted: what has moved since the fold, in visit order ----
+        // ---- accepted: beta, the carried gradients, what has moved since the fold (in visit order) ----
         for (int u0 = 0; u0 < cnt; u0 += kCsThreads) {
             const int u = u0 + tid;
-            const int64_t k = u < cnt ? b.uk[u] : 0;
-            const bool neu = u < cnt && b.hs[u] != 0.0 && !b.inmoved[k];
-            int tot;
-            const int at = nmoved + cs_block_rank(neu, tot, s_w);
-            if (neu) { b.moved[at] = (int32_t)k; b.inmoved[k] = 1; }
+            const bool in = u < cnt;
+            const int uc = in ? u : 0;
+            const int64_t k = cnt > 0 ? T.k[uc] : 0;
+            const double hv = cnt > 0 ? b.hs[uc] : 0.0;
+            const bool neu[1] = {in && hv != 0.0 && b.inmoved[k] == 0};
+            int at[1];
+            const int tot = cs_rank<1>(neu, at, s_w);
+            if (neu[0]) { b.moved[nmoved + at[0]] = (int32_t)k; b.inmoved[k] = 1; }
+            if (in) { b.gxp[k] = pass_id; b.gx[k] = T.gx[u]; b.beta[k] = T.beta[u]; }
             nmoved += tot;
         }
+        pass_id += 1;
         TV0 += tv_pass; q = q_end;
+        __syncthreads();
+        lap(5);
 
         // ---- ProximalBase's SparseIterate, in visit order: a pre-prox non-zero appends a slot (x[k] += b/a), cdprox! stores
         // the value; a settled visit of the least-squares losses with g_k != 0 leaves a zero in a slot of its own ----
-        for (int i0 = 0; i0 < L; i0 += kCsThreads) {
-            const int i = i0 + tid;
-            const bool valid = i < L;
-            const int k = valid ? b.list[i] : 0;
-            bool app = false;
-            if (valid && b.i2s[k] == 0) {
-                if (full && b.setflag[k]) app = !sqrt_loss && b.g[k] != 0.0;
-                else { const int j = b.vb[k]; app = b.touched[j] != 0 || b.newval[j] != 0.0; }
+        {
+            const int cm1 = cnt > 0 ? cnt - 1 : 0;
+            for (int i0 = 0; i0 < L; i0 += kCsThreads * E) {
+                int k[E], isl[E], sf[E], jv[E], tch[E];
+                bool app[E], valid[E];
+                double gk[E], nvv[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const int i = i0 + tid * E + e; valid[e] = i < L; const int ic = min(i, Lm1); k[e] = direct ? ic : b.list[ic]; }
+#pragma unroll
+                for (int e = 0; e < E; ++e) { isl[e] = b.i2s[k[e]]; sf[e] = full ? b.setflag[k[e]] : 0; jv[e] = b.vb[k[e]]; gk[e] = b.g[k[e]]; }
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const int j = min(max(jv[e], 0), cm1); tch[e] = b.touched[j]; nvv[e] = b.newval[j]; }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool settled_app = !sqrt_loss & (gk[e] != 0.0);
+                    const bool visited_app = (cnt > 0) & ((tch[e] != 0) | (nvv[e] != 0.0));
+                    app[e] = valid[e] & (isl[e] == 0) & (sf[e] ? settled_app : visited_app);
+                }
+                int sl[E];
+                const int tot = cs_rank<E>(app, sl, s_w);
+#pragma unroll
+                for (int e = 0; e < E; ++e) if (app[e]) { b.s2i[nnz + sl[e]] = k[e]; b.i2s[k[e]] = nnz + sl[e] + 1; }
+                nnz += tot;
             }
-            int tot;
-            const int sl = nnz + cs_block_rank(app, tot, s_w);
-            if (app) { b.s2i[sl] = k; b.i2s[k] = sl + 1; }
-            nnz += tot;
         }
         __syncthreads();
+        lap(6);
         // ---- dropzeros!: swap-with-last (sparse_iterate.hpp) as a match of holes and fillers (small_solve.hpp) ----
         {
-            int m = 0;
-            for (int s0 = 0; s0 < nnz; s0 += kCsThreads) { const int s = s0 + tid; m += cs_block_count(s < nnz && b.beta[b.s2i[s < nnz ? s : 0]] != 0.0, s_w); }
+            int mine = 0;
+            for (int s0 = 0; s0 < nnz; s0 += kCsThreads * E) {
+                int ks[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) ks[e] = b.s2i[min(s0 + tid + e * kCsThreads, nnz - 1)];
+#pragma unroll
+                for (int e = 0; e < E; ++e) mine += ((s0 + tid + e * kCsThreads < nnz) & (b.beta[ks[e]] != 0.0)) ? 1 : 0;
+            }
+            const int m = cs_block_sum(mine, s_w);
             if (m != nnz) {
                 int nh = 0, nf = 0;
-                for (int s0 = 0; s0 < m; s0 += kCsThreads) {
-                    const int s = s0 + tid;
-                    const bool hole = s < m && b.beta[b.s2i[s < m ? s : 0]] == 0.0;
-                    int tot;
-                    const int at = nh + cs_block_rank(hole, tot, s_w);
-                    if (hole) b.holes[at] = s;
+                for (int s0 = 0; s0 < m; s0 += kCsThreads * E) {
+                    bool hole[E];
+                    int s[E], at[E], ks[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { s[e] = s0 + tid * E + e; ks[e] = b.s2i[min(s[e], nnz - 1)]; }
+#pragma unroll
+                    for (int e = 0; e < E; ++e) hole[e] = (s[e] < m) & (b.beta[ks[e]] == 0.0);
+                    const int tot = cs_rank<E>(hole, at, s_w);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) if (hole[e]) b.holes[nh + at[e]] = s[e];
                     nh += tot;
                 }
-                for (int s1 = nnz; s1 > m; s1 -= kCsThreads) {          // chunks from the end; inside a chunk thread 0 is the last slot
-                    const int s = s1 - 1 - tid;
-                    const bool fil = s >= m && b.beta[b.s2i[s >= m ? s : m]] != 0.0;
-                    int tot;
-                    const int at = nf + cs_block_rank(fil, tot, s_w);
-                    if (fil) b.fills[at] = s;
+                for (int s1 = nnz; s1 > m; s1 -= kCsThreads * E) {       // chunks from the end; inside a chunk thread 0's first element is the last slot
+                    bool fil[E];
+                    int s[E], at[E], ks[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { s[e] = s1 - 1 - (tid * E + e); ks[e] = b.s2i[max(s[e], 0)]; }
+#pragma unroll
+                    for (int e = 0; e < E; ++e) fil[e] = (s[e] >= m) & (b.beta[ks[e]] != 0.0);
+                    const int tot = cs_rank<E>(fil, at, s_w);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) if (fil[e]) b.fills[nf + at[e]] = s[e];
                     nf += tot;
                 }
                 __syncthreads();
@@ -357,13 +507,14 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             }
         }
         passes += 1; visits += L; cov_visits += cnt; settled_total += L - cnt; lastH = s_ctrl.maxH;
-        if (full) full_passes += 1;
+        if (full) { full_passes += 1; cov_visits_full += cnt; }
         prev_conv = conv;
         conv = lastH < optTol;
         if (prev_conv && conv) { status = kCsConverged; break; }
     }
 
     // ---- what the host needs: the support in slot order with its values, the moves still pending on g ----
+    __syncthreads();
     for (int s = tid; s < nnz; s += kCsThreads) { const int k = b.s2i[s]; b.out_sup_idx[s] = k; b.out_sup_val[s] = b.beta[k]; }
     for (int m = tid; m < nmoved; m += kCsThreads) { const int km = b.moved[m]; b.out_moved_idx[m] = km; b.out_moved_val[m] = b.beta[km] - b.bfold[km]; }
     {   // exact re-checks were counted per thread
@@ -378,8 +529,11 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         ctl->rng = rng; ctl->q = q; ctl->nnz = nnz; ctl->prev_conv = prev_conv ? 1 : 0; ctl->conv = conv ? 1 : 0;
         ctl->inject_count = inject_count; ctl->status = status; ctl->n_list = n_list; ctl->n_moved = nmoved;
         ctl->domain_error = dom_any; ctl->passes = passes; ctl->full_passes = full_passes; ctl->visits = visits;
-        ctl->cov_visits = cov_visits; ctl->settled = settled_total; ctl->folds = folds; ctl->exact_rechecks = exact_rechecks;
+        ctl->cov_visits = cov_visits; ctl->cov_visits_full = cov_visits_full; ctl->settled = settled_total; ctl->folds = folds; ctl->exact_rechecks = exact_rechecks;
         ctl->maxH = lastH;
+        lap(7);
+        for (int i = 0; i < 8; ++i) ctl->ticks[i] = (int64_t)tph[i];
+        ctl->cycles = (int64_t)(__builtin_amdgcn_s_memtime() - cyc0); ctl->ticks_total = (int64_t)(__builtin_amdgcn_s_memrealtime() - tick0);
     }
 }
 
@@ -389,4 +543,230 @@ __global__ __launch_bounds__(256) void k_cov_colmax(double* __restrict__ colmax,
     if (k >= p || k == j) return;
     const double v = fabs(col[k]);
     if (v > colmax[k] || v != v) colmax[k] = v;       // (a NaN entry poisons the bound: nothing is certified against it)
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+enum { kCsNotNow = 0, kCsFinished = 1, kCsAgain = 2 };
+
+inline size_t cs_align(size_t v) { return (v + 255) / 256 * 256; }
+
+// scratch of the kernel (122 p bytes of device memory) and the pinned block it reads the support from and writes its
+// results into (zero-copy, as the one-launch solve's: nothing is copied around the launch)
+int32_t cs_alloc(cdh_handle h) {
+    GradCache& c = h->gc;
+    if (c.cs_dev || !c.cs_enabled) return CDH_OK;
+    const size_t p = (size_t)h->p;
+    const size_t dev_bytes = 11 * cs_align(8 * p) + 5 * cs_align(8 * p) + 9 * cs_align(4 * p) + 2 * cs_align(p) + cs_align(8 * p) /* colmax */;
+    const size_t pin_bytes = cs_align(sizeof(CovSolveCtl)) + 4 * cs_align(4 * p) + 2 * cs_align(8 * p);
+    void* dev_view = nullptr;
+    bool fits = hipMalloc((void**)&c.cs_dev, dev_bytes) == hipSuccess && hipHostMalloc((void**)&c.cs_pin, pin_bytes) == hipSuccess &&
+                hipHostGetDevicePointer(&dev_view, c.cs_pin, 0) == hipSuccess;
+    if (!fits) (void)hipGetLastError();
+    CHK(all_ranks_agree(h, fits, &fits));
+    if (!fits) {
+        if (c.cs_dev) (void)hipFree(c.cs_dev);
+        if (c.cs_pin) (void)hipHostFree(c.cs_pin);
+        c.cs_dev = nullptr; c.cs_pin = nullptr; c.cs_enabled = false;
+        return CDH_OK;
+    }
+    c.cs_pin_dev = static_cast<char*>(dev_view);
+    CovSolveBufs& b = c.cs_bufs;
+    char* d = c.cs_dev;
+    auto take = [&](size_t bytes) { char* q = d; d += cs_align(bytes); return q; };
+    b.p = h->p;
+    b.gx = (double*)take(8 * p); b.bfold = (double*)take(8 * p); b.bsnap = (double*)take(8 * p); b.hs = (double*)take(8 * p);
+    b.newval = (double*)take(8 * p); b.qs = (double*)take(8 * p); b.tv = (double*)take(8 * p); b.pendv = (double*)take(8 * p);
+    b.ubeta = (double*)take(8 * p); b.uom = (double*)take(8 * p); b.ugx = (double*)take(8 * p);
+    b.uk = (int64_t*)take(8 * p); b.poff = (int64_t*)take(8 * p); b.voff = (int64_t*)take(8 * p); b.uprev = (int64_t*)take(8 * p); b.iota = (int64_t*)take(8 * p);
+    b.touched = (int32_t*)take(4 * p); b.s2i = (int32_t*)take(4 * p); b.i2s = (int32_t*)take(4 * p); b.list = (int32_t*)take(4 * p);
+    b.vb = (int32_t*)take(4 * p); b.moved = (int32_t*)take(4 * p); b.holes = (int32_t*)take(4 * p); b.fills = (int32_t*)take(4 * p);
+    b.gxp = (int32_t*)take(4 * p);
+    b.setflag = (uint8_t*)take(p); b.inmoved = (uint8_t*)take(p);
+    c.d_colmax = (double*)take(8 * p);
+    b.colmax = c.d_colmax;
+    // the pinned block, as the host and as the device address it
+    size_t o = cs_align(sizeof(CovSolveCtl));
+    auto pin = [&](size_t bytes) { const size_t at = o; o += cs_align(bytes); return at; };
+    const size_t o_in = pin(4 * p), o_si = pin(4 * p), o_mi = pin(4 * p), o_li = pin(4 * p), o_sv = pin(8 * p), o_mv = pin(8 * p);
+    c.cs_ctl = reinterpret_cast<CovSolveCtl*>(c.cs_pin);
+    c.cs_in_sup = reinterpret_cast<int32_t*>(c.cs_pin + o_in);
+    c.cs_out_sup_idx = reinterpret_cast<int32_t*>(c.cs_pin + o_si); c.cs_out_moved_idx = reinterpret_cast<int32_t*>(c.cs_pin + o_mi);
+    c.cs_out_list = reinterpret_cast<int32_t*>(c.cs_pin + o_li);
+    c.cs_out_sup_val = reinterpret_cast<double*>(c.cs_pin + o_sv); c.cs_out_moved_val = reinterpret_cast<double*>(c.cs_pin + o_mv);
+    b.in_sup = reinterpret_cast<const int32_t*>(c.cs_pin_dev + o_in);
+    b.out_sup_idx = reinterpret_cast<int32_t*>(c.cs_pin_dev + o_si); b.out_moved_idx = reinterpret_cast<int32_t*>(c.cs_pin_dev + o_mi);
+    b.out_list = reinterpret_cast<int32_t*>(c.cs_pin_dev + o_li);
+    b.out_sup_val = reinterpret_cast<double*>(c.cs_pin_dev + o_sv); b.out_moved_val = reinterpret_cast<double*>(c.cs_pin_dev + o_mv);
+    c.cs_old.assign(p, 0.0);
+    c.colmax_slots = 0;
+    // dynamic LDS: the tracked coordinates' Gram block and, for shuffled sweeps, the shuffle's two p-sized arrays
+    c.cs_lds_budget = kCsLdsBudget;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cov_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCsLdsBudget) != hipSuccess) {
+        (void)hipGetLastError();
+        c.cs_lds_budget = (size_t)36 * 1024;          // what the default 64 KB leave next to the kernel's static arrays
+    }
+    c.cs_shuffle_ok = 8 * p + 8 * 16 * 16 + (kCsTrackedBytes + 8) * 16 <= c.cs_lds_budget;
+    return CDH_OK;
+}
+
+// M_k of the kernel's bound, brought up to date with the columns the device store holds
+int32_t cs_update_colmax(cdh_handle h) {
+    GradCache& c = h->gc;
+    if (c.colmax_slots > c.dev_slots) c.colmax_slots = 0;          // the store was refilled from slot 0
+    if (c.colmax_slots == c.dev_slots) return CDH_OK;
+    if (c.colmax_slots == 0) HIPCHK(h, hipMemsetAsync(c.d_colmax, 0, sizeof(double) * (size_t)h->p, h->stream));
+    std::vector<int64_t> coord((size_t)c.dev_slots, -1);
+    for (int64_t k = 0; k < h->p; ++k) if (c.slot[(size_t)k] >= 0 && c.slot[(size_t)k] < c.dev_slots) coord[(size_t)c.slot[(size_t)k]] = k;
+    for (int64_t s_ = c.colmax_slots; s_ < c.dev_slots; ++s_)
+        hipLaunchKernelGGL(k_cov_colmax, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_colmax, c.d_G + s_ * h->p,
+                           coord[(size_t)s_], h->p);
+    HIPCHK(h, hipGetLastError());
+    c.colmax_slots = c.dev_slots;
+    return CDH_OK;
+}
+
+// The passes of a solve from `*iter` on, on the device, as far as the gradient cache can serve them.
+//   kCsFinished  the solve is over (converged, or maxIter passes done): statistics and the iterate are up to date
+//   kCsAgain     the kernel stopped for something the host has now supplied (Gram columns, a fresh g): call again
+//   kCsNotNow    the next pass runs the round-3 way (solve() below): the cache is not engaged, or the kernel undid a pass
+int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched, cdh_stats* st, bool* prev_conv, bool* conv,
+                  int64_t* iter, int* outcome) {
+    GradCache& c = h->gc;
+    *outcome = kCsNotNow;
+    c.prep_state = 0;
+    if (!c.cs_enabled || !c.cov || !gc_applicable(h) || c.mode == 0 || h->p < kScreenMinPass || h->p > ((int64_t)1 << 26)) return CDH_OK;
+    if (o->randomize && (h->p > kCsShuffleMaxP || !c.cs_shuffle_ok)) return CDH_OK;
+    const bool full = *conv;
+    double cert_abs = 0.0;
+    if (full) {
+        // (the gate of run_pass: full passes over dense iterates are not screened at all)
+        if (!h->screening || h->x.nnz() * 4 > h->p) return CDH_OK;
+        bool go = false;
+        CHK(gc_prepare_full(h, &go, &cert_abs));
+        c.prep_state = go ? 1 : 2; c.prep_cert_abs = cert_abs;      // gc_full_pass, if it comes to that, does not prepare twice
+        if (!go) return CDH_OK;
+    } else {
+        if (!c.valid || !c.d_G) return CDH_OK;
+        if (gc_support_outgrown(h)) { gc_invalidate(h, false); return CDH_OK; }
+        if (c.cov_since_ref > c.refresh_after) CHK(gc_rereference(h));
+        for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return CDH_OK;
+        gc_fold(h);
+        if (!c.valid) return CDH_OK;
+        if (h->loss == CDH_SQRT) CHK(gc_ensure_q(h));
+        CHK(gc_cert_abs(h, &cert_abs));
+    }
+    if (!c.d_G || !c.d_scan || !c.moved.empty() || c.dev_slots != (int64_t)c.G.size()) return CDH_OK;
+    for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) if (c.slot[(size_t)h->x.coord(s_)] < 0) return CDH_OK;
+    if (h->x.nnz() > gc_max_support(h)) return CDH_OK;
+    CHK(cs_alloc(h));
+    if (!c.cs_enabled) return CDH_OK;
+    if (!c.slot_dev_ok) {             // the columns were dropped since the map last went down (a new X): the kernel asks d_slot who has one
+        HIPCHK(h, hipMemcpyAsync(c.d_slot, c.slot.data(), sizeof(int32_t) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        c.slot_dev_ok = true;
+    }
+    CHK(cs_update_colmax(h));
+    CHK(gc_need_dev_g(h));
+    c.prep_state = 0;                                               // from here on the state moves: a later pass prepares afresh
+
+    CovSolveCtl& ctl = *c.cs_ctl;
+    ctl.lambda0 = h->ctrl.lambda0; ctl.n_total = (double)h->n_total; ctl.optTol = o->optTol; ctl.cert_abs = cert_abs;
+    ctl.max_passes = o->maxIter - *iter;
+    ctl.cov_budget = std::max<int64_t>(0, c.refresh_after - c.cov_since_ref);
+    ctl.loss = h->loss; ctl.has_omega = h->has_omega ? 1 : 0; ctl.randomize = o->randomize ? 1 : 0;
+    {
+        int64_t lim = gc_max_support(h);
+        if (!(c.mode == 3 || gc_short_columns(h))) lim = std::min<int64_t>(lim, h->n_total / gc_rows_per_nnz(h));
+        ctl.nnz_limit = (int32_t)std::min<int64_t>(lim, 0x7fffffff);
+    }
+    ctl.busy_limit = kGcBusy; ctl.inject_every = c.inject_rollback; ctl.pad0 = ctl.pad1 = 0;
+    ctl.rng = sched.state(); ctl.q = c.q;
+    ctl.nnz = (int32_t)h->x.nnz(); ctl.prev_conv = *prev_conv ? 1 : 0; ctl.conv = *conv ? 1 : 0; ctl.inject_count = c.inject_count;
+    ctl.status = -1; ctl.n_list = 0; ctl.n_moved = 0;
+    for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) c.cs_in_sup[s_] = (int32_t)h->x.coord(s_);
+    CovSolveBufs b = c.cs_bufs;
+    b.g = c.d_g; b.Gcols = c.d_G; b.slot = c.d_slot; b.a = c.d_a; b.omega = h->omega; b.beta = h->beta;
+    const size_t shuffle_bytes = o->randomize ? 8 * (size_t)h->p : 0;
+    // the tracked coordinates' Gram block (8 u^2 bytes) and arrays (kCsTrackedBytes u, rounded up) next to the shuffle's
+    int ucap = kCsUcapMax;
+    while (ucap > 8 && 8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > c.cs_lds_budget) ucap -= 4;
+    const unsigned lds = (unsigned)(8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes);
+    hipLaunchKernelGGL(k_cov_solve, dim3(1), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    c.n_cs_launches += 1;
+    if (ctl.status < 0) return fail(h, CDH_HIP_ERROR, "the device-resident solve returned no status");
+
+    // ---- the iterate: the support in its new slot order; what changed becomes pending residual updates ----
+    const int64_t nnz_old = h->x.nnz();
+    std::vector<int64_t> old_idx((size_t)nnz_old);
+    for (int64_t s_ = 0; s_ < nnz_old; ++s_) { old_idx[(size_t)s_] = h->x.coord(s_); c.cs_old[(size_t)h->x.coord(s_)] = h->x.slot_value(s_); }
+    auto note_move = [&](int64_t k, double d) {
+        if (d == 0.0) return;
+        h->dots_valid = false;        // the residual the handle stands for moves
+        if (!h->r_in_pending[(size_t)k]) { h->r_in_pending[(size_t)k] = 1; h->r_pending_list.push_back(k); }
+        h->r_pending[(size_t)k] += d;
+        if (c.beta_ok) c.beta_ref[(size_t)k] += d;
+    };
+    h->x.clear();
+    for (int32_t s_ = 0; s_ < ctl.nnz; ++s_) {
+        const int64_t k = c.cs_out_sup_idx[s_];
+        const double v = c.cs_out_sup_val[s_];
+        if (v == 0.0) { h->x.set(k, 1.0); h->x.set(k, 0.0); }     // a stored zero keeps its slot (the caller put it there)
+        else h->x.set(k, v);
+        note_move(k, v - c.cs_old[(size_t)k]);
+        c.cs_old[(size_t)k] = 0.0;
+    }
+    for (int64_t k : old_idx) { if (c.cs_old[(size_t)k] != 0.0) note_move(k, -c.cs_old[(size_t)k]); c.cs_old[(size_t)k] = 0.0; }
+    // ---- the cache: moves still pending on g, r'r, the counters ----
+    for (int32_t m = 0; m < ctl.n_moved; ++m) {
+        const int64_t k = c.cs_out_moved_idx[m];
+        const double v = c.cs_out_moved_val[m];
+        if (v == 0.0) continue;
+        c.dbeta[(size_t)k] += v;
+        if (!c.in_moved[(size_t)k]) { c.in_moved[(size_t)k] = 1; c.moved.push_back(k); }
+    }
+    if (ctl.folds > 0) c.g_host_ok = false;
+    if (h->loss == CDH_SQRT) c.q = ctl.q;
+    c.inject_count = ctl.inject_count;
+    c.n_passes += ctl.full_passes; c.n_dev_passes += ctl.full_passes; c.n_certified += ctl.settled;
+    c.n_cov += ctl.cov_visits; c.cov_since_ref += ctl.cov_visits; c.n_cs_passes += ctl.passes; c.n_cs_folds += ctl.folds; c.n_cs_exact += ctl.exact_rechecks;
+    for (int i = 0; i < 8; ++i) c.cs_ticks[i] += ctl.ticks[i];
+    c.cs_cycles += ctl.cycles; c.cs_ticks_total += ctl.ticks_total;
+    c.n_exact += ctl.cov_visits_full;
+    if (ctl.domain_error) h->domain_error = true;
+    sched.set_state(ctl.rng);
+    *prev_conv = ctl.prev_conv != 0; *conv = ctl.conv != 0; *iter += ctl.passes;
+    st->passes += ctl.passes; st->full_passes += ctl.full_passes; st->visits += ctl.visits;
+    if (ctl.passes > 0) st->maxH = ctl.maxH;
+
+    switch (ctl.status) {
+    case kCsConverged: st->converged = 1; *outcome = kCsFinished; return CDH_OK;
+    case kCsMaxIter: *outcome = kCsFinished; return CDH_OK;
+    case kCsRollback: c.n_rollbacks += 1; return CDH_OK;            // the host walks this pass the careful way
+    case kCsOutgrown: return CDH_OK;                                // gc_prepare_full / gc_ready_for_cov draw the consequences
+    case kCsRefresh: CHK(gc_rereference(h)); *outcome = kCsAgain; return CDH_OK;
+    case kCsBusy:     // many inactive coordinates about to move: back off (1, 2, 4 ... 16 plain passes), as gc_pass_device does
+        c.cooldown = c.backoff; c.backoff = std::min(16, 2 * c.backoff);
+        gc_invalidate(h, false);
+        c.prep_state = 2;
+        return CDH_OK;
+    case kCsNeedColumns: {
+        if (ctl.passes == 0 && c.cs_stalled) { c.cs_stalled = false; return CDH_OK; }   // (twice in a row without progress: the old way)
+        c.cs_stalled = ctl.passes == 0;
+        c.backoff = 1;
+        std::vector<int64_t> enter(c.cs_out_list, c.cs_out_list + ctl.n_list);
+        for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return fail(h, CDH_BAD_ARG, "gradient cache: a moved coordinate has no Gram column");
+        gc_fold(h);
+        if (!c.valid) return CDH_OK;
+        CHK(gc_need_host_g(h));
+        GcThresholds T{h, h->ctrl.lambda0, (double)h->n_total, 0.0, cert_abs};
+        if (h->loss == CDH_SQRT) { CHK(gc_ensure_q(h)); T.rnorm = std::sqrt(c.q); }
+        CHK(gc_fetch_entering(h, enter, [&](int64_t k) { return T.cert(k); }, [&](int64_t k) { return T.ratio(k); }));
+        if (c.mode == 0) return CDH_OK;
+        *outcome = kCsAgain;
+        return CDH_OK;
+    }
+    default: return fail(h, CDH_HIP_ERROR, "the device-resident solve returned an unknown status");
+    }
 }

@@ -1,0 +1,39 @@
+// cov_solve_types.hpp -- what the device-resident pass loop (cov_solve.hpp) exchanges with the host: declared ahead of
+// the handle, which keeps these blocks.
+#pragma once
+#include <stdint.h>
+
+enum { kCsConverged = 0, kCsMaxIter = 1, kCsNeedColumns = 2, kCsRollback = 3, kCsBusy = 4, kCsRefresh = 5, kCsOutgrown = 6 };
+
+struct CovSolveCtl {
+    // in
+    double lambda0, n_total, optTol, cert_abs;
+    int64_t max_passes;          // passes this launch may run (maxIter - those already done)
+    int64_t cov_budget;          // covariance-form visits this launch may make before g is due to be re-read from X
+    int32_t loss, has_omega, randomize, nnz_limit /* support size beyond which the cache stands aside */;
+    int32_t busy_limit, inject_every, pad0, pad1;
+    // in / out
+    uint64_t rng;
+    double q;                    // r'r (sqrt-lasso)
+    int32_t nnz, prev_conv, conv, inject_count;
+    // out
+    int32_t status, n_list /* kCsNeedColumns / kCsBusy: coordinates that want a Gram column (out_list) */, n_moved, domain_error;
+    int64_t passes, full_passes, visits, cov_visits, cov_visits_full, settled, folds, exact_rechecks;
+    double maxH;
+    int64_t cycles, ticks_total; // shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) the launch ran for
+    int64_t ticks[8];            // 100 MHz ticks the kernel spent per phase (list, scan, exact gradients, visits, re-check, accept, bookkeeping, dropzeros! + the rest)
+};
+
+struct CovSolveBufs {
+    int64_t p;
+    double* g; const double* Gcols; const int32_t* slot; const double* a; const double* colmax; const double* omega;
+    double* beta;
+    double *gx, *bfold, *bsnap, *hs, *newval, *qs, *tv, *pendv, *ubeta, *uom, *ugx;
+    int64_t *uk, *poff, *voff, *uprev, *iota;
+    int32_t *touched, *s2i, *i2s, *list, *vb, *moved, *holes, *fills, *gxp;
+    uint8_t *setflag, *inmoved;
+    const int32_t* in_sup;                   // the support in slot order (pinned host memory, read once)
+    int32_t *out_sup_idx, *out_moved_idx, *out_list;   // pinned host memory, written once at the end
+    double *out_sup_val, *out_moved_val;
+};
+

@@ -123,6 +123,7 @@ int32_t gc_dev_upload(cdh_handle h) {
     c.dev_slots = have;
     HIPCHK(h, hipMemcpyAsync(c.d_slot, c.slot.data(), sizeof(int32_t) * (size_t)p, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    c.slot_dev_ok = true;
     return CDH_OK;
 }
 
@@ -298,6 +299,7 @@ void cov_apply_visit(cdh_handle h, int64_t k, int i) {
     h->x.set(k, h->h_newval[i]);
     const double hv = h->h_hs[i];
     if (hv == 0.0) return;
+    h->dots_valid = false;            // the residual the handle stands for moves
     if (!h->r_in_pending[(size_t)k]) { h->r_in_pending[(size_t)k] = 1; h->r_pending_list.push_back(k); }
     h->r_pending[(size_t)k] += hv;
     if (hv == hv && h->gc.beta_ok) h->gc.beta_ref[(size_t)k] += hv;
@@ -341,10 +343,19 @@ int32_t cov_reject(cdh_handle h, const int64_t* idx0, int m) {
 // new reference point
 int32_t gc_validate(cdh_handle h) {
     GradCache& c = h->gc;
-    CHK(col_dots(h, 0, h->p, h->r, h->has_w));
-    std::vector<double> cd((size_t)(2 * h->p));
-    HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * h->p, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<double> cd;
+    if (h->dots_valid && h->dots_w == h->has_w && (int64_t)h->dots_stash.size() == 2 * h->p) {
+        // the dots of all p columns with this very residual were taken a moment ago (_findLambdaMax, coordinate_descent.jl:118-149,
+        // or cdh_xt_r, before the first solve of a path): that pass over X is the reference pass
+        cd = h->dots_stash;
+        h->n_dots_adopted += 1;
+    } else {
+        CHK(col_dots(h, 0, h->p, h->r, h->has_w));
+        cd.resize((size_t)(2 * h->p));
+        HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * h->p, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->dots_stash = cd; h->dots_valid = true; h->dots_w = h->has_w;
+    }
     for (int64_t k = 0; k < h->p; ++k) { c.g[(size_t)k] = cd[(size_t)(2 * k)]; c.a[(size_t)k] = cd[(size_t)(2 * k + 1)]; }
     for (int64_t j : c.moved) { c.dbeta[(size_t)j] = 0.0; c.in_moved[(size_t)j] = 0; }
     c.moved.clear();
@@ -411,6 +422,15 @@ int32_t gc_rereference(cdh_handle h) {
     return CDH_OK;
 }
 
+// G[(b0 + b) p + k] <- the cross products of one k_cross batch (records of 64 x 32, tile-major): the batch's columns, slot-major
+__global__ __launch_bounds__(256) void k_cross_unpack(const double* __restrict__ cross, int64_t p, int b0, int nbc, double* __restrict__ Gcols) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p) return;
+    const int64_t L = k / kCrossA, i = k % kCrossA;
+    for (int b = 0; b < nbc; ++b)
+        Gcols[(int64_t)(b0 + b) * p + k] = cross[L * kCrossRec + ((i >> 4) * kCrossTB + (b >> 4)) * 256 + (i & 15) * 16 + (b & 15)];
+}
+
 // Gram columns G_j = X'X_j for the coordinates in `cols` (those not cached yet), up to 32 per pass over X
 int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
     GradCache& c = h->gc;
@@ -456,6 +476,13 @@ int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
             c.slot[(size_t)todo[b0 + (size_t)b]] = (int32_t)(c.G.size() - 1);
         }
         c.n_batches += 1; c.n_columns += nbc;
+        // the batch's columns go into the device store straight from the cross-product records where it has room (no trip
+        // through the host for them: 32 pageable uploads of p doubles each were ~1 ms per batch at p = 5000)
+        if (c.cov && c.d_G && c.dev_slots + nbc == (int64_t)c.G.size() && (int64_t)c.G.size() <= c.dev_slots_cap) {
+            hipLaunchKernelGGL(k_cross_unpack, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_cross, h->p, (int)c.dev_slots, nbc, c.d_G);
+            HIPCHK(h, hipGetLastError());
+            c.dev_slots += nbc;
+        }
         CHK(gc_dev_upload(h));
     }
     return CDH_OK;
@@ -706,7 +733,8 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
     double cert_abs = 0.0;
     {
         bool go = false;
-        CHK(gc_prepare_full(h, &go, &cert_abs));
+        if (c.prep_state) { go = c.prep_state == 1; cert_abs = c.prep_cert_abs; c.prep_state = 0; }   // cov_solve has prepared this pass
+        else CHK(gc_prepare_full(h, &go, &cert_abs));
         if (!go) return CDH_OK;
     }
     const double lam = h->ctrl.lambda0, nt = (double)h->n_total;

@@ -523,6 +523,7 @@ int32_t small_solve(cdh_handle h, const cdh_options* o, const double* lambdas, i
     // what moved becomes pending residual updates (r_actual = r_virtual + X * pending: sync_r applies them before anything
     // reads r) and, for a gradient cache that holds a reference, pending moves like those of any other visit
     GradCache& c = h->gc;
+    h->dots_valid = false;             // the residual the handle stands for moves with the iterate
     if (from_c) {                      // r was never read and is not touched: it stands for the new iterate, to be formed on demand
         if (c.valid || c.beta_ok) gc_invalidate(h, false);
         drop_r_pending(h);

@@ -91,6 +91,10 @@ public:
         }
     }
 
+    // the generator's state: the device-resident pass loops carry it themselves (small_solve.hpp, cov_solve.hpp)
+    uint64_t state() const { return state_; }
+    void set_state(uint64_t s) { state_ = s; }
+
 private:
     uint64_t next() {
         uint64_t z = (state_ += 0x9E3779B97F4A7C15ull);

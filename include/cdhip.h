@@ -222,6 +222,17 @@ int32_t cdh_set_gradient_cache(cdh_handle h, int32_t mode);
  * lasso.jl:250-252 runs on a caller's loss object, whose settings are the caller's). */
 int32_t cdh_get_gradient_cache(cdh_handle h, int32_t *out_mode);
 int32_t cdh_cache_stats(cdh_handle h, int64_t *out10);
+/* While the cache serves the passes of a solve, the pass loop of _coordinateDescent! itself (coordinate_descent.jl:74-91:
+ * reset!(it, full), _cdPass!, dropzeros!, the convergence test) runs on the device -- one workgroup, one host round trip per
+ * solve instead of two per pass; it comes back early only for what the host alone can give (Gram columns of coordinates
+ * about to enter, a re-reference, the careful walk after a certificate broke).  Same iterates, support order and pass
+ * counts.  On by default (environment CDH_COV_SOLVE=0, or on = 0 here, keeps the pass loop on the host).
+ * cdh_device_loop_stats: out12 = {launches of the loop, passes run inside it, in-kernel folds of pending moves into the
+ * gradient, certificates re-checked with the exact gradient because the bound did not cover them, and the time the kernel
+ * spent per phase in 10 ns ticks: building visit lists, the scan, exact gradients of the visited coordinates, the visits,
+ * the re-check, accepting a pass, the SparseIterate bookkeeping, dropzeros! and the rest}. */
+int32_t cdh_set_device_loop(cdh_handle h, int32_t on);
+int32_t cdh_device_loop_stats(cdh_handle h, int64_t *out12);
 /* How far the carried gradient has been from X'r whenever it was taken afresh from X (after CDH_GC_REFRESH
  * covariance-form visits, or right now with rereference_now != 0: one dots-only pass over X):
  *   drift = max_k |g_carried[k] - X_k'r| / thr_k,   thr_k = lambda0 n omega_k (sqrt-lasso: lambda0 omega_k ||r||)

@@ -1,0 +1,150 @@
+"""The device-resident pass loop of cache-served solves (csrc/cov_solve.hpp): `_coordinateDescent!`
+(coordinate_descent.jl:65-92) with ONE host round trip per solve while the gradient cache serves the passes.
+
+Bar: beta within 1e-10 of the oracle at every lambda, and the SAME discrete outcomes -- pass counts, visit counts,
+support ORDER (ProximalBase's SparseIterate replayed on the device: the order of the support is the visit order of the
+next active pass) -- as the oracle's per-coordinate sweep, ordered and shuffled, for every loss; the loop on and off
+agree bit for bit in what they report.  The bound that lets a full pass skip the p x moves Gram update
+(|g_k(t)| <= |g_k| + M_k TV(t)) is exercised where it is loose: strongly correlated columns.
+"""
+import numpy as np
+import pytest
+
+import coordinatedescent_jl_amd as cd
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+BETA_TOL = 1e-10
+
+
+def _problem(seed, n, p, s, noise=1.0, rho=0.0):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, p))
+    if rho:
+        for j in range(1, p):                       # an AR(1) chain of columns: corr(X_j, X_{j+1}) = rho
+            X[:, j] = rho * X[:, j - 1] + np.sqrt(1 - rho * rho) * X[:, j]
+    X = np.asfortranarray(X)
+    Y = X[:, :s] @ rng.standard_normal(s) + noise * rng.standard_normal(n)
+    return rng, X, Y
+
+
+def _losses(kind, Y, X, w):
+    if kind == "sqrt":
+        return cd.CDSqrtLassoLoss(Y, X), O.CDSqrtLassoLoss(Y, X)
+    if kind == "wls":
+        return cd.CDWeightedLSLoss(Y, X, w), O.CDWeightedLSLoss(Y, X, w)
+    return cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+
+
+@pytest.mark.parametrize("kind", ["ls", "wl1", "sqrt", "wls"])
+@pytest.mark.parametrize("rand", [False, True], ids=["ordered", "random"])
+def test_device_loop_path_matches_oracle(kind, rand):
+    """A 16-lambda warm-started path (lasso.jl:250-252): every lambda against the oracle, loop on; then the same
+    path with the loop off must report the same iterates, orders and counts."""
+    rng, X, Y = _problem(71, 2500, 600, 12)
+    X *= rng.uniform(0.5, 2.0, size=600)
+    w = rng.random(2500) + 0.5
+    om = (rng.random(600) + 0.5) if kind == "wl1" else None
+    top = 3.4 if kind == "sqrt" else 0.3
+    lams = np.exp(np.linspace(np.log(top), np.log((0.6 if kind == "sqrt" else 0.1) * top), 16))
+    o = dict(maxIter=3000, optTol=1e-10, randomize=rand, seed=29)
+    f, fo = _losses(kind, Y, X, w)
+    xo, want = O.SparseIterate(600), []
+    for lam in lams:
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam, om), O.CDOptions(**o))
+        want.append((xo.dense().copy(), xo.nzval2ind.tolist(), st["passes"], st["visits"]))
+    assert 8 < xo.nnz < 200
+    got = {}
+    for loop in (True, False):
+        f, _ = _losses(kind, Y, X, w)
+        f.set_gradient_cache(3)
+        f.set_onchip_solve(False)
+        f.set_device_loop(loop)
+        x = cd.SparseIterate(600)
+        rec = []
+        for lam, (beta, sup, passes, visits) in zip(lams, want):
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(**o))
+            np.testing.assert_allclose(x.dense(), beta, rtol=0, atol=BETA_TOL)
+            assert x.nzval2ind.tolist() == sup, (loop, lam)
+            assert (f.last_stats["passes"], f.last_stats["visits"]) == (passes, visits), (loop, lam)
+            assert f.last_stats["converged"]
+            rec.append(x.dense().copy())
+        np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-9)          # the residual catches up with the moves when read
+        ls, cs = f.device_loop_stats(), f.cache_stats()
+        if loop:
+            assert ls["launches"] >= len(lams) and ls["passes"] > 2 * len(lams), ls
+            assert cs["device_passes"] >= len(lams) and cs["settled_visits"] > 5 * cs["exact_visits"], cs
+            # about one launch per solve plus one per batch of entering coordinates: not one per pass
+            assert ls["launches"] <= len(lams) + 2 * cs["gram_batches"] + 4, (ls, cs)
+        else:
+            assert ls["launches"] == 0
+        got[loop] = rec
+        f.close()
+    for a, b_ in zip(got[True], got[False]):
+        np.testing.assert_allclose(a, b_, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("rho", [0.9, 0.99])
+def test_device_loop_on_correlated_columns_where_the_bound_is_loose(rho):
+    """corr(X_j, X_{j+1}) = rho: M_k is of the order of a_k, the bound fails for whole neighbourhoods of the support,
+    which then get their exact gradients or a fold -- and the answer is still the oracle's, counts and order included."""
+    rng, X, Y = _problem(73, 1500, 400, 10, rho=rho)
+    lams = np.exp(np.linspace(np.log(0.5), np.log(0.02), 12))
+    o = dict(maxIter=20000, optTol=1e-10, randomize=False)
+    fo, xo = O.CDLeastSquaresLoss(Y, X), O.SparseIterate(400)
+    f = cd.CDLeastSquaresLoss(Y, X)
+    f.set_gradient_cache(3)
+    f.set_onchip_solve(False)
+    x = cd.SparseIterate(400)
+    for lam in lams:
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"], lam
+    ls = f.device_loop_stats()
+    assert ls["launches"] > 0 and ls["passes"] > 0, ls
+    f.close()
+
+
+def test_device_loop_cold_start_and_maxiter():
+    """The 51 continuation solves of a cold start (coordinate_descent.jl:24-37) each run through the loop; a solve cut
+    off by maxIter stops at the same pass with the same iterate."""
+    rng, X, Y = _problem(79, 2000, 300, 8)
+    fo, f = O.CDLeastSquaresLoss(Y, X), cd.CDLeastSquaresLoss(Y, X)
+    f.set_gradient_cache(3)
+    f.set_onchip_solve(False)
+    for opts in (dict(maxIter=2000, optTol=1e-10, randomize=False, warmStart=False),
+                 dict(maxIter=2000, optTol=1e-10, randomize=True, seed=3, warmStart=False),
+                 dict(maxIter=3, optTol=1e-12, randomize=False, warmStart=True)):
+        x, xo = cd.SparseIterate(300), O.SparseIterate(300)
+        cd.coordinateDescent_(x, f, cd.ProxL1(0.03), cd.CDOptions(**opts))
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(0.03), O.CDOptions(**opts))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert f.last_stats["passes"] == st["passes"] and f.last_stats["visits"] == st["visits"], opts
+        assert bool(f.last_stats["converged"]) == bool(st["converged"]), opts
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist(), opts
+    assert f.device_loop_stats()["launches"] >= 51
+    f.close()
+
+
+def test_device_loop_undone_passes_leave_no_trace(monkeypatch):
+    """CDH_GC_INJECT_ROLLBACK=2: every second full pass of the loop is declared failed after it ran; the kernel puts
+    beta back, the host walks that pass the careful way, and the loop takes over again."""
+    monkeypatch.setenv("CDH_GC_INJECT_ROLLBACK", "2")
+    rng, X, Y = _problem(83, 2200, 500, 10)
+    lams = np.exp(np.linspace(np.log(0.3), np.log(0.03), 10))
+    for rand in (False, True):
+        o = dict(maxIter=3000, optTol=1e-10, randomize=rand, seed=5)
+        fo, xo = O.CDLeastSquaresLoss(Y, X), O.SparseIterate(500)
+        f = cd.CDLeastSquaresLoss(Y, X)
+        f.set_gradient_cache(3)
+        f.set_onchip_solve(False)
+        x = cd.SparseIterate(500)
+        for lam in lams:
+            st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+            np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+            assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"], (rand, lam)
+        assert f.cache_stats()["rollbacks"] > 0 and f.device_loop_stats()["passes"] > 0
+        np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-9)
+        f.close()

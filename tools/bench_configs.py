@@ -42,7 +42,7 @@ def cfg3(n=2_000_000, p=5000, nlam=100):
     sync(f)
     dt = time.perf_counter() - t0
     return dict(config="cfg3 lasso path", n=n, p=p, lambdas=nlam, seconds=dt, passes=passes, visits=visits,
-                visits_per_s=visits / dt, nnz_last=nnz[-1], nnz_max=max(nnz), cache=f.cache_stats(),
+                visits_per_s=visits / dt, nnz_last=nnz[-1], nnz_max=max(nnz), cache=f.cache_stats(), device_loop=f.device_loop_stats(),
                 drift=f.cache_drift(rereference_now=True), beta_checksum=float(np.sum(np.abs(x.dense()))))
 
 
@@ -99,7 +99,7 @@ def wls_path(n=4_000_000, p=2000, nlam=30):
     sync(f)
     dt = time.perf_counter() - t0
     return dict(config="weighted-LS loss, warm-started path", n=n, p=p, lambdas=nlam, seconds=dt, passes=passes, visits=visits,
-                nnz_last=x.nnz, cache_mode=int(os.environ.get("CFG_CACHE", "2")), cache=f.cache_stats(),
+                nnz_last=x.nnz, cache_mode=int(os.environ.get("CFG_CACHE", "2")), cache=f.cache_stats(), device_loop=f.device_loop_stats(),
                 beta_checksum=float(np.sum(np.abs(x.dense()))))
 
 
