@@ -231,13 +231,13 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         lap(0);
 
         // ---- the scan: which positions are visited ("unsettled"), in visit order ----
-        int cnt = 0, nocol = 0, nzero = 0, nsupp = 0;
+        int cnt = 0, nocol = 0, nzero = 0, nsupp = 0, nexc = 0;
         for (int attempt = 0;; ++attempt) {
             cnt = 0; nocol = 0;
-            int nz_mine = 0, ns_mine = 0;
+            int nz_mine = 0, ns_mine = 0, nx_mine = 0;
             const double thr_base = lambda0 * (sqrt_loss ? sqrt(q) : n_total);
             for (int i0 = 0; i0 < L; i0 += kCsThreads * E) {
-                int k[E], sl[E];
+                int k[E], sl[E], isl[E];
                 bool valid[E], uns[E], nc[E], st[E];
                 double gk[E], bk[E], ak[E], om[E], mk[E];
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 }
 #pragma unroll
                 for (int e = 0; e < E; ++e) {                        // every load unconditional (clamped index): all in flight together
-                    gk[e] = b.g[k[e]]; bk[e] = b.beta[k[e]]; sl[e] = b.slot[k[e]];
+                    gk[e] = b.g[k[e]]; bk[e] = b.beta[k[e]]; sl[e] = b.slot[k[e]]; isl[e] = b.i2s[k[e]];
                     ak[e] = b.a[k[e]]; mk[e] = b.colmax[k[e]]; om[e] = has_omega ? b.omega[k[e]] : 1.0;
                 }
 #pragma unroll
@@ -260,6 +260,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     nc[e] = uns[e] & (sl[e] < 0);
                     nz_mine += (st[e] & (gk[e] == 0.0)) ? 1 : 0;
                     ns_mine += (uns[e] & (bk[e] != 0.0)) ? 1 : 0;
+                    nx_mine += (st[e] & ((gk[e] == 0.0) | (isl[e] != 0))) ? 1 : 0;
                 }
                 int ru[E], rc[E], tu, tc;
                 cs_rank2<E>(uns, nc, ru, rc, tu, tc, s_w);
@@ -268,13 +269,14 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     if (valid[e]) {
                         b.vb[k[e]] = cnt + ru[e];          // visited: its index in the visit list; settled: visits before its turn
                         if (full) b.setflag[k[e]] = st[e] ? 1 : 0;
-                        if (uns[e]) b.uk[cnt + ru[e]] = k[e];
+                        if (uns[e]) { b.uk[cnt + ru[e]] = k[e]; b.upos[cnt + ru[e]] = i0 + tid * E + e; }
                         if (nc[e]) b.out_list[nocol + rc[e]] = k[e];
                     }
                 cnt += tu; nocol += tc;
             }
             nzero = cs_block_sum(nz_mine, s_w);
             nsupp = cs_block_sum(ns_mine, s_w);
+            nexc = cs_block_sum(nx_mine, s_w);
             // many inactive coordinates fail the bound only because it has grown loose -- or one without a Gram column does,
             // which would send the host for a pass over X: fold (exact g for everybody) and look again
             if (attempt == 0 && nmoved > 0 && ((full && cnt - nsupp > kCsNearMax) || nocol > 0)) { fold(); pass_id += 2; continue; }
@@ -432,9 +434,94 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         __syncthreads();
         lap(5);
 
+        // ---- ProximalBase's SparseIterate.  The straightforward replay (further down) appends a slot for every settled
+        // coordinate of a least-squares pass -- p of them -- only for dropzeros! to sweep them out again.  All of them hold
+        // zeros, so none can be a filler, and only those whose slot would lie below the final count m can be a hole: with
+        // A-index alpha = (appends before it) that is alpha < m - nnz_old <= (entrants).  And alpha of a VISITED coordinate
+        // follows from its position alone when every settled coordinate before it appended (no exception: nexc == 0):
+        //   alpha_j = (pos_j - j) + (visited appenders before j).
+        // So the final slot order is assembled from the old slots and the visited appenders only -- (nnz + cnt)-sized loops.
+        const bool analytic = sqrt_loss || !full || nexc == 0;
+        if (analytic) {
+            const int nnz_old = nnz;
+            // 1. the visited coordinates that append: their A-index; those that stay non-zero ("entrants")
+            int nA = 0, nE = 0;
+            for (int u0 = 0; u0 < cnt; u0 += kCsThreads) {
+                const int u = u0 + tid;
+                const bool in = u < cnt;
+                const int uc = in ? u : 0;
+                const int64_t k = b.uk[uc];
+                const double nvv = b.newval[uc];
+                const bool app[1] = {in && b.i2s[k] == 0 && (b.touched[uc] != 0 || nvv != 0.0)};
+                int r[1];
+                const int tot = cs_rank<1>(app, r, s_w);
+                const int alpha = ((full && !sqrt_loss) ? b.upos[uc] - u : 0) + nA + r[0];
+                if (in) b.aidx[u] = app[0] ? (nvv != 0.0 ? alpha : -2 - alpha) : -1;      // >= 0: entrant; <= -2: a zero of its own; -1: no append
+                nE += cs_block_sum((app[0] && nvv != 0.0) ? 1 : 0, s_w);
+                nA += tot;
+            }
+            int nzo_mine = 0;
+            for (int s = tid; s < nnz_old; s += kCsThreads) nzo_mine += b.beta[b.s2i[s]] != 0.0 ? 1 : 0;
+            const int m = cs_block_sum(nzo_mine, s_w) + nE;
+            const int na_total = ((full && !sqrt_loss) ? (L - cnt) : 0) + nA;
+            if (na_total != 0 || m != nnz_old) {
+                // 2. entrants whose slot lies below m take it; the other slots below m that were appended hold zeros: holes
+                const int X = max(m - nnz_old, 0);
+                for (int a = tid; a < X; a += kCsThreads) b.occ[a] = 0;
+                __syncthreads();
+                for (int u = tid; u < cnt; u += kCsThreads) {
+                    const int al = b.aidx[u];
+                    if (al >= 0 && al < X) { const int64_t k = b.uk[u]; b.occ[al] = 1; b.s2i[nnz_old + al] = (int32_t)k; b.i2s[k] = nnz_old + al + 1; }
+                }
+                __syncthreads();
+                int nh = 0, nf = 0;
+                const int lim = min(m, nnz_old);
+                for (int s0 = 0; s0 < lim; s0 += kCsThreads) {             // holes among the old slots, ascending
+                    const int s = s0 + tid;
+                    const bool hole[1] = {s < lim && b.beta[b.s2i[s < lim ? s : 0]] == 0.0};
+                    int at[1];
+                    const int tot = cs_rank<1>(hole, at, s_w);
+                    if (hole[0]) b.holes[nh + at[0]] = s;
+                    nh += tot;
+                }
+                for (int a0 = 0; a0 < X; a0 += kCsThreads) {               // ... then among the appended ones
+                    const int a = a0 + tid;
+                    const bool hole[1] = {a < X && b.occ[a < X ? a : 0] == 0};
+                    int at[1];
+                    const int tot = cs_rank<1>(hole, at, s_w);
+                    if (hole[0]) b.holes[nh + at[0]] = nnz_old + a;
+                    nh += tot;
+                }
+                for (int u1 = cnt; u1 > 0; u1 -= kCsThreads) {             // fillers, from the last slot down: entrants at or beyond m ...
+                    const int u = u1 - 1 - tid;
+                    const int al = u >= 0 ? b.aidx[u] : -1;
+                    const bool fil[1] = {u >= 0 && al >= X};
+                    int at[1];
+                    const int tot = cs_rank<1>(fil, at, s_w);
+                    if (fil[0]) b.fills[nf + at[0]] = (int32_t)b.uk[u];
+                    nf += tot;
+                }
+                for (int s1 = nnz_old; s1 > m; s1 -= kCsThreads) {         // ... then old slots at or beyond m that hold non-zeros
+                    const int s = s1 - 1 - tid;
+                    const bool fil[1] = {s >= m && b.beta[b.s2i[s >= m ? s : m]] != 0.0};
+                    int at[1];
+                    const int tot = cs_rank<1>(fil, at, s_w);
+                    if (fil[0]) b.fills[nf + at[0]] = b.s2i[s];
+                    nf += tot;
+                }
+                __syncthreads();
+                for (int s = tid; s < nnz_old; s += kCsThreads) { const int ks = b.s2i[s]; if (b.beta[ks] == 0.0) b.i2s[ks] = 0; }
+                __syncthreads();
+                const int nmatch = min(nh, nf);                            // (equal by construction)
+                for (int r = tid; r < nmatch; r += kCsThreads) { const int kf = b.fills[r]; b.s2i[b.holes[r]] = kf; b.i2s[kf] = b.holes[r] + 1; }
+                __syncthreads();
+                nnz = m;
+            }
+            lap(6);
+        }
         // ---- ProximalBase's SparseIterate, in visit order: a pre-prox non-zero appends a slot (x[k] += b/a), cdprox! stores
         // the value; a settled visit of the least-squares losses with g_k != 0 leaves a zero in a slot of its own ----
-        {
+        if (!analytic) {
             const int cm1 = cnt > 0 ? cnt - 1 : 0;
             for (int i0 = 0; i0 < L; i0 += kCsThreads * E) {
                 int k[E], isl[E], sf[E], jv[E], tch[E];
@@ -462,7 +549,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         __syncthreads();
         lap(6);
         // ---- dropzeros!: swap-with-last (sparse_iterate.hpp) as a match of holes and fillers (small_solve.hpp) ----
-        {
+        if (!analytic) {
             int mine = 0;
             for (int s0 = 0; s0 < nnz; s0 += kCsThreads * E) {
                 int ks[E];
@@ -556,7 +643,7 @@ int32_t cs_alloc(cdh_handle h) {
     GradCache& c = h->gc;
     if (c.cs_dev || !c.cs_enabled) return CDH_OK;
     const size_t p = (size_t)h->p;
-    const size_t dev_bytes = 11 * cs_align(8 * p) + 5 * cs_align(8 * p) + 9 * cs_align(4 * p) + 2 * cs_align(p) + cs_align(8 * p) /* colmax */;
+    const size_t dev_bytes = 11 * cs_align(8 * p) + 5 * cs_align(8 * p) + 12 * cs_align(4 * p) + 2 * cs_align(p) + cs_align(8 * p) /* colmax */;
     const size_t pin_bytes = cs_align(sizeof(CovSolveCtl)) + 4 * cs_align(4 * p) + 2 * cs_align(8 * p);
     void* dev_view = nullptr;
     bool fits = hipMalloc((void**)&c.cs_dev, dev_bytes) == hipSuccess && hipHostMalloc((void**)&c.cs_pin, pin_bytes) == hipSuccess &&
@@ -580,7 +667,7 @@ int32_t cs_alloc(cdh_handle h) {
     b.uk = (int64_t*)take(8 * p); b.poff = (int64_t*)take(8 * p); b.voff = (int64_t*)take(8 * p); b.uprev = (int64_t*)take(8 * p); b.iota = (int64_t*)take(8 * p);
     b.touched = (int32_t*)take(4 * p); b.s2i = (int32_t*)take(4 * p); b.i2s = (int32_t*)take(4 * p); b.list = (int32_t*)take(4 * p);
     b.vb = (int32_t*)take(4 * p); b.moved = (int32_t*)take(4 * p); b.holes = (int32_t*)take(4 * p); b.fills = (int32_t*)take(4 * p);
-    b.gxp = (int32_t*)take(4 * p);
+    b.gxp = (int32_t*)take(4 * p); b.upos = (int32_t*)take(4 * p); b.aidx = (int32_t*)take(4 * p); b.occ = (int32_t*)take(4 * p);
     b.setflag = (uint8_t*)take(p); b.inmoved = (uint8_t*)take(p);
     c.d_colmax = (double*)take(8 * p);
     b.colmax = c.d_colmax;

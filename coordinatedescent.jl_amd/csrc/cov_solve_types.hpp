@@ -30,7 +30,7 @@ struct CovSolveBufs {
     double* beta;
     double *gx, *bfold, *bsnap, *hs, *newval, *qs, *tv, *pendv, *ubeta, *uom, *ugx;
     int64_t *uk, *poff, *voff, *uprev, *iota;
-    int32_t *touched, *s2i, *i2s, *list, *vb, *moved, *holes, *fills, *gxp;
+    int32_t *touched, *s2i, *i2s, *list, *vb, *moved, *holes, *fills, *gxp, *upos, *aidx, *occ;
     uint8_t *setflag, *inmoved;
     const int32_t* in_sup;                   // the support in slot order (pinned host memory, read once)
     int32_t *out_sup_idx, *out_moved_idx, *out_list;   // pinned host memory, written once at the end
