@@ -227,6 +227,7 @@ struct cdh_handle_s {
     Ctrl ctrl{};
     bool has_omega = false, has_w = false, y_set = false;
     std::vector<double> h_omega;  // host copy of the penalty weights (thresholds, objective)
+    bool omega_dev_ok = false;    // the device's omega holds h_omega
     cdh::SupportList x;
     int mode = CDH_SWEEP_BLOCK, blockB = 32;   // the default (cdh_create: 64 on short fp64 columns); cdh_set_sweep_mode changes it
     // The default width is chosen from the rank-LOCAL row count, and near-equal row shards can fall on opposite sides of the
@@ -1459,10 +1460,16 @@ static int32_t cdh_generate_impl(cdh_handle h, uint64_t seed, int64_t s, double 
 
 static int32_t cdh_set_penalty_impl(cdh_handle h, double lambda0, const double* omega, int64_t n_omega) {
     HIPCHK(h, hipSetDevice(h->device));
+    bool uploaded = false;
     if (omega) {
         if (n_omega != h->p) return fail(h, CDH_DIM_MISMATCH, "length(g.lambda) != numCoordinates(f)");
-        HIPCHK(h, hipMemcpyAsync(h->omega, omega, sizeof(double) * h->p, hipMemcpyHostToDevice, h->stream));
-        h->h_omega.assign(omega, omega + h->p);
+        // a path hands over the same weights at every lambda (lasso.jl:251: ProxL1(lambda, stdX)): what the device holds is kept
+        if (!(h->omega_dev_ok && (int64_t)h->h_omega.size() == h->p && std::memcmp(h->h_omega.data(), omega, sizeof(double) * (size_t)h->p) == 0)) {
+            HIPCHK(h, hipMemcpyAsync(h->omega, omega, sizeof(double) * h->p, hipMemcpyHostToDevice, h->stream));
+            h->h_omega.assign(omega, omega + h->p);
+            h->omega_dev_ok = true;
+            uploaded = true;
+        }
         h->has_omega = true;
     } else {
         h->has_omega = false;
@@ -1471,7 +1478,7 @@ static int32_t cdh_set_penalty_impl(cdh_handle h, double lambda0, const double* 
     h->ctrl.has_omega = h->has_omega ? 1 : 0;
     // the control block goes to the device at the start of every chunk (run_chunk); only the caller's
     // weight buffer, borrowed for this call, has to be consumed before returning
-    if (omega) HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (uploaded) HIPCHK(h, hipStreamSynchronize(h->stream));
     return CDH_OK;
 }
 

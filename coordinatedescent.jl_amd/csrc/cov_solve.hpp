@@ -35,6 +35,7 @@ constexpr int kCsWaves = kCsThreads / 64;
 constexpr int kCsNearMax = 96;           // inactive coordinates failing the bound beyond which the kernel folds and scans again
 constexpr int64_t kCsShuffleMaxP = 12288;   // the shuffle's two p-sized int arrays must fit LDS
 constexpr size_t kCsLdsBudget = (size_t)134 * 1024;   // dynamic LDS next to ~24 KB of static arrays (160 KB per CU)
+constexpr int kCsTrackedMargin = 24;     // room in the tracked list for entering and near-threshold coordinates next to the support
 constexpr int kCsUcapMax = 124;          // tracked coordinates whose Gram block is kept in LDS (124 x 124 doubles = 120 KB)
 
 // Ranks inside a block, E positions per thread (thread t owns positions base + E t .. base + E t + E - 1: rank order is
@@ -232,7 +233,17 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
 
         // ---- the scan: which positions are visited ("unsettled"), in visit order ----
         int cnt = 0, nocol = 0, nzero = 0, nsupp = 0, nexc = 0;
-        for (int attempt = 0;; ++attempt) {
+        bool scanned = false;
+        if (!full) {                     // an active pass visits its whole list: nothing to classify (unless a column is missing)
+            int nc_mine = 0;
+            for (int i = tid; i < L; i += kCsThreads) {
+                const int k = b.list[i];
+                b.uk[i] = k; b.upos[i] = i; b.vb[k] = i;
+                nc_mine += b.slot[k] < 0 ? 1 : 0;
+            }
+            if (cs_block_sum(nc_mine, s_w) == 0) { cnt = L; nsupp = L; scanned = true; }
+        }
+        for (int attempt = 0; !scanned; ++attempt) {
             cnt = 0; nocol = 0;
             int nz_mine = 0, ns_mine = 0, nx_mine = 0;
             const double thr_base = lambda0 * (sqrt_loss ? sqrt(q) : n_total);
@@ -745,6 +756,17 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     if (!c.d_G || !c.d_scan || !c.moved.empty() || c.dev_slots != (int64_t)c.G.size()) return CDH_OK;
     for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) if (c.slot[(size_t)h->x.coord(s_)] < 0) return CDH_OK;
     if (h->x.nnz() > gc_max_support(h)) return CDH_OK;
+    // One workgroup serves supports whose Gram block fits its LDS: beyond that every visit's update of the tracked gradients
+    // is a gather through one CU (measured at benchmark/cd_bench.jl's shape, 774 non-zeros: 0.38 s against 0.11 s for the
+    // pass-by-pass kernels, which spread that update over the chip) -- larger supports stay with those.
+    const size_t shuffle_bytes = o->randomize ? 8 * (size_t)h->p : 0;
+    int ucap = kCsUcapMax;
+    {
+        const size_t budget = c.cs_lds_budget ? c.cs_lds_budget : kCsLdsBudget;
+        while (ucap > 8 && 8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > budget) ucap -= 4;
+    }
+    const int64_t support_cap = ucap - kCsTrackedMargin;
+    if (h->x.nnz() > support_cap) return CDH_OK;
     CHK(cs_alloc(h));
     if (!c.cs_enabled) return CDH_OK;
     if (!c.slot_dev_ok) {             // the columns were dropped since the map last went down (a new X): the kernel asks d_slot who has one
@@ -764,7 +786,7 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     {
         int64_t lim = gc_max_support(h);
         if (!(c.mode == 3 || gc_short_columns(h))) lim = std::min<int64_t>(lim, h->n_total / gc_rows_per_nnz(h));
-        ctl.nnz_limit = (int32_t)std::min<int64_t>(lim, 0x7fffffff);
+        ctl.nnz_limit = (int32_t)std::min<int64_t>({lim, support_cap, (int64_t)0x7fffffff});
     }
     ctl.busy_limit = kGcBusy; ctl.inject_every = c.inject_rollback; ctl.pad0 = ctl.pad1 = 0;
     ctl.rng = sched.state(); ctl.q = c.q;
@@ -773,10 +795,10 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) c.cs_in_sup[s_] = (int32_t)h->x.coord(s_);
     CovSolveBufs b = c.cs_bufs;
     b.g = c.d_g; b.Gcols = c.d_G; b.slot = c.d_slot; b.a = c.d_a; b.omega = h->omega; b.beta = h->beta;
-    const size_t shuffle_bytes = o->randomize ? 8 * (size_t)h->p : 0;
     // the tracked coordinates' Gram block (8 u^2 bytes) and arrays (kCsTrackedBytes u, rounded up) next to the shuffle's
-    int ucap = kCsUcapMax;
+    ucap = kCsUcapMax;
     while (ucap > 8 && 8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > c.cs_lds_budget) ucap -= 4;
+    if (h->x.nnz() > ucap - kCsTrackedMargin) return CDH_OK;     // (the budget the runtime really granted is smaller)
     const unsigned lds = (unsigned)(8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes);
     hipLaunchKernelGGL(k_cov_solve, dim3(1), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
     HIPCHK(h, hipGetLastError());
