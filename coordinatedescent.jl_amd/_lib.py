@@ -142,6 +142,7 @@ def lib():
         "cdh_onchip_stats": [vp, P(i64)],
         "cdh_onchip_last": [vp, P(i64)],
         "cdh_cache_drift": [vp, i32, P(f64)],
+        "cdh_cache_gram_column": [vp, i64, vp, P(f64)],
         "cdh_set_screening": [vp, i32],
         "cdh_comm_unique_id": [vp],
         "cdh_comm_init": [vp, vp, i32, i32],

@@ -324,6 +324,12 @@ class _HipLoss(CoordinateDifferentiableFunction):
         return dict(zip(("passes", "settled_visits", "exact_visits", "reference_passes", "gram_batches", "gram_columns",
                          "covariance_visits", "residual_catchups", "rollbacks", "device_passes"), [int(v) for v in out]))
 
+    def cache_gram_column(self, k):
+        """(X'X_k as the gradient cache holds it, the relative error its entries are declared to carry); k 1-based."""
+        out, eps = np.zeros(self.p), C.c_double()
+        check(self._L.cdh_cache_gram_column(self._h, int(k), _vp(out), C.byref(eps)), self._h)
+        return out, eps.value
+
     def set_device_loop(self, on=True):
         """The pass loop of a cache-served solve on the device (cdh_set_device_loop; on by default)."""
         check(self._L.cdh_set_device_loop(self._h, int(bool(on))), self._h)

@@ -804,6 +804,10 @@ template <typename T, int NG> int32_t launch_gram_chunk(cdh_handle h, int m) {
         if (use_lt) {
             if constexpr (NG == 1) {
                 go(k_gramstep<T, 1, true, true>);
+            } else if constexpr (NG == 4 && sizeof(T) == 4) {
+                // (never reached: use_lt is false for fp32 B = 64 -- its LDS-transposed variants spilled 160 - 280 bytes per lane
+                // and are not instantiated)
+                go(k_gramstep<T, NG, true>);
             } else {
                 if (short_chunks) go(k_gramstep<T, NG, true, true, 1>); else go(k_gramstep<T, NG, true, true>);
             }
@@ -1873,6 +1877,19 @@ int32_t cdh_cache_stats(cdh_handle h, int64_t* out10) {
     out10[3] = c.n_validate; out10[4] = c.n_batches; out10[5] = c.n_columns;
     out10[6] = c.n_cov; out10[7] = c.n_reconcile; out10[8] = c.n_rollbacks;
     out10[9] = c.n_dev_passes;
+    return CDH_OK;
+}
+
+int32_t cdh_cache_gram_column(cdh_handle h, int64_t k1, double* out_p, double* out_eps) {
+    NEED_H(h);
+    NEED_P(h, out_p);
+    if (k1 < 1 || k1 > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
+    const GradCache& c = h->gc;
+    if (c.slot.empty() || c.slot[(size_t)(k1 - 1)] < 0 || (size_t)c.slot[(size_t)(k1 - 1)] >= c.G.size())
+        return fail(h, CDH_BAD_ARG, "the gradient cache holds no Gram column for this coordinate");
+    const std::vector<double>& col = c.G[(size_t)c.slot[(size_t)(k1 - 1)]];
+    std::memcpy(out_p, col.data(), sizeof(double) * (size_t)h->p);
+    if (out_eps) *out_eps = h->dtype == CDH_F32 ? 5.9604644775390625e-8 * kCrossF32EpsFactor / std::sqrt((double)h->n_total) : 0.0;
     return CDH_OK;
 }
 

@@ -45,11 +45,12 @@ int32_t gc_size(cdh_handle h) {   // first use on this handle
     const char* gxe = getenv("CDH_CROSS_GX");
     const int64_t nsuper = (launches + kGramWaves - 1) / kGramWaves;   // a block's four waves take four column groups
     c.cross_GX = (int)std::max<int64_t>(1, std::min<int64_t>(nsuper, gxe ? atoi(gxe) : 4));
-    c.cross_J = (int)std::max<int64_t>(1, std::min<int64_t>(nslabs, ((int64_t)kCrossOcc * h->cus) / c.cross_GX));
+    const int64_t occ = h->dtype == CDH_F32 ? cross_occ<float>() : cross_occ<double>();
+    c.cross_J = (int)std::max<int64_t>(1, std::min<int64_t>(nslabs, (occ * h->cus) / c.cross_GX));
     // short columns have few row slabs to hand out (n = 3000: two): the resident blocks they leave unused take further
     // column super-groups instead (benchmark/cd_bench.jl's shape: 8 blocks walked 79 column groups, 0.78 ms per batch of a
     // 120 MB X; 40 blocks: one group per wave)
-    if (!gxe) c.cross_GX = (int)std::min<int64_t>(nsuper, std::max<int64_t>(c.cross_GX, ((int64_t)kCrossOcc * h->cus) / c.cross_J));
+    if (!gxe) c.cross_GX = (int)std::min<int64_t>(nsuper, std::max<int64_t>(c.cross_GX, (occ * h->cus) / c.cross_J));
     // (a handle whose first sizing failed may be asked again: what a failed attempt got was freed below)
     bool fits = hipMalloc((void**)&c.d_cross, sizeof(double) * (size_t)launches * kCrossRec) == hipSuccess &&
                 hipMalloc((void**)&c.d_cross_part, sizeof(double) * (size_t)launches * (size_t)c.cross_J * kCrossRec) == hipSuccess &&
@@ -162,6 +163,7 @@ int32_t gc_need_dev_g(cdh_handle h) {
 // visit would read.  A rounding of relative size 2^-24 per element and rewrite, U rewrites since the residual was last
 // rebuilt, uncorrelated with the column: |X_k'(r_fp32 - r)| ~ 2^-24 sqrt(U a_k r'r / n); with r'r <= y'y along a path
 // and a factor 64 of safety:   cert_abs sqrt(a_k),  cert_abs = 64 * 2^-24 * sqrt((U + 1) y'y / n).   fp64 storage: 0.
+constexpr double kCrossF32EpsFactor = 512.0;   // eps_G = 2^-24 * this / sqrt(n_total)
 int32_t gc_cert_abs(cdh_handle h, double* out) {
     GradCache& c = h->gc;
     *out = 0.0;
@@ -173,7 +175,12 @@ int32_t gc_cert_abs(cdh_handle h, double* out) {
         c.yy = h->h_red[1];
         c.yy_ok = true;
     }
-    *out = 64.0 * 5.9604644775390625e-8 * std::sqrt((double)(h->r_roundings + 1) * c.yy / (double)h->n_total);
+    // ... plus (round 4) what the Gram entries themselves carry: k_cross takes fp32 storage on the fp32 matrix pipe, 256-row
+    // partial sums in fp32 folded into fp64 tiles, so an entry is good to eps_G sqrt(a_i a_j) with eps_G ~ 2^-24 * 128 / sqrt(n)
+    // for fully correlated columns (measured: tests/test_gpu_parity.py::test_fp32_gram_columns_carry_the_declared_error); a
+    // carried gradient updated with them is off by at most eps_G sqrt(a_k) sum_j |dbeta_j| sqrt(a_j) <~ eps_G sqrt(a_k y'y).
+    // Declared with a factor 4: 2^-24 * 512 / sqrt(n) -- eight times the residual's own term at U = 0.
+    *out = 5.9604644775390625e-8 * std::sqrt(c.yy / (double)h->n_total) * (64.0 * std::sqrt((double)(h->r_roundings + 1)) + kCrossF32EpsFactor);
     return CDH_OK;
 }
 
@@ -452,10 +459,10 @@ int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
             using T = std::remove_pointer_t<decltype(t)>;
             const dim3 grid((unsigned)c.cross_GX, (unsigned)c.cross_J), block(64 * kGramWaves);
             if (h->has_w)   // G = X'WX (CDWeightedLSLoss: cd_differentiable_function.jl:177-182)
-                hipLaunchKernelGGL((k_cross<T, true>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc,
+                hipLaunchKernelGGL((k_cross<T, true, 2, 2, cross_occ<T>()>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc,
                                    (const T*)h->w, c.d_cross_part);
             else
-                hipLaunchKernelGGL((k_cross<T, false>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc,
+                hipLaunchKernelGGL((k_cross<T, false, 2, 2, cross_occ<T>()>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, c.d_cols, nbc,
                                    (const T*)nullptr, c.d_cross_part);
             return CDH_OK;
         }));

@@ -21,6 +21,8 @@
 // from each of 16 columns, and A == B for the diagonal tile.  X' r uses the same A with
 // B = r broadcast over j (every column of D then holds c).
 #pragma once
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace cdk {
@@ -77,7 +79,7 @@ template <int NG> struct LtTile {
 // column groups x chunk vectors, one load instruction covering NG/KS previous columns, the column
 // groups summed by a butterfly.
 template <typename T, int NG, bool NT_, bool LT = false, int KS = NG>
-__global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gramstep(
+__global__ __launch_bounds__(64 * kGramWaves, (NG >= 2 || LT) ? 2 : 3) void k_gramstep(
     const T* __restrict__ X, int64_t ld, int64_t nvec, const T* __restrict__ w, T* __restrict__ r,
     const int64_t* __restrict__ idx, const double* __restrict__ hs, int pos0, int nb, int nprev,
     double* __restrict__ partials) {
@@ -132,14 +134,23 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
     // LT: load instruction t of a sub-chunk covers columns t*NG .. t*NG+NG-1; this lane takes
     // column t*NG + lt_cl at vector lt_vl of the sub-chunk
     const int lt_cl = lane / LTT::SV, lt_vl = lane % LTT::SV;
-    const V* lt_col[LT ? 16 : 1];
+    // B = 64 with long chunks sits at the register limit of 2 waves per SIMD (10 accumulator tiles, 16 operand vectors in
+    // flight and their fragments): its 16 column pointers per lane live in LDS and are fetched per sub-chunk (round 4: they
+    // cost 32 VGPRs and the kernel spilled 8 dwords to scratch)
+    constexpr bool LDSCOL = LT && NG == 4 && KS == NG && sizeof(T) == 8;
+    __shared__ const V* s_col[LDSCOL ? 16 * NG : 1];
+    const V* lt_col[(LT && !LDSCOL) ? 16 : 1];
     unsigned lt_act = 0;
     if constexpr (LT) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int col = t * NG + lt_cl;
             if (col < nb) lt_act |= 1u << t;
-            lt_col[t] = reinterpret_cast<const V*>(X + idx[pos0 + (col < nb ? col : 0)] * ld);
+            if constexpr (!LDSCOL) lt_col[t] = reinterpret_cast<const V*>(X + idx[pos0 + (col < nb ? col : 0)] * ld);
+        }
+        if constexpr (LDSCOL) {
+            if (threadIdx.x < 16 * NG) s_col[threadIdx.x] = reinterpret_cast<const V*>(X + idx[pos0 + ((int)threadIdx.x < nb ? (int)threadIdx.x : 0)] * ld);
+            __syncthreads();
         }
     }
 
@@ -243,9 +254,11 @@ __global__ __launch_bounds__(64 * kGramWaves, (NG == 4 || LT) ? 2 : 3) void k_gr
                 V xc[NL];
                 const int64_t vsub = v0 + 4 * u0 + lt_vl;       // this lane's vector in the sub-chunk
 #pragma unroll
-                for (int t = 0; t < NL; ++t)
-                    xc[t] = (((lt_act >> t) & 1) && vsub < nvec) ? ld_stream<NT_>(lt_col[t] + vsub)
-                                                                 : vzero((V*)nullptr);
+                for (int t = 0; t < NL; ++t) {
+                    const V* colp;
+                    if constexpr (LDSCOL) colp = s_col[t * NG + lt_cl]; else colp = lt_col[t];
+                    xc[t] = (((lt_act >> t) & 1) && vsub < nvec) ? ld_stream<NT_>(colp + vsub) : vzero((V*)nullptr);
+                }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int t = 0; t < NL; ++t) s_x[wave][(t * NG + lt_cl) * XS + lt_vl] = xc[t];
@@ -595,7 +608,10 @@ constexpr int kCrossTA = 4, kCrossTB = 2, kCrossA = 16 * kCrossTA, kCrossB = 16 
               kCrossRec = kCrossTA * kCrossTB * 256;
 constexpr int kCrossSlab = 1024;         // vectors per row slab (fp64: 2048 rows)
 constexpr int kCrossOcc = 3;             // blocks per CU of k_cross (its 44 KB of LDS and 151 registers allow three)
+// ... of the fp64 kernel.  The fp32 one keeps fp32 tiles next to the fp64 running tiles (32 more registers): two blocks per CU
+template <typename T> constexpr int cross_occ() { return sizeof(T) == 4 ? 2 : kCrossOcc; }
 constexpr int kX2SV = 8;                          // vectors per sub-chunk
+constexpr int kCrossFold = 8;                     // fp32 storage: sub-chunks (of 32 rows) per fp32 partial sum
 constexpr int kX2BSlots = kCrossB * kX2SV;        // 16-byte slots of the block's B sub-chunk
 constexpr int kX2SPS = kCrossSlab / kX2SV;        // sub-chunks per row slab
 template <int AUX>
@@ -618,6 +634,7 @@ __global__ __launch_bounds__(64 * kGramWaves, OCC) void k_cross(const T* __restr
                                                                const T* __restrict__ w, double* __restrict__ partials) {
     using V = typename VecOf<T>::V;
     constexpr int NV = VecOf<T>::N;
+    constexpr bool F32 = sizeof(T) == 4;
     constexpr int HS = 32 * kX2SV;                    // 16-byte slots of one ring slot (32 columns x 8 vectors)
     constexpr int EV = 5 + (HASW ? 1 : 0), OD = 4;    // DMA instructions a wave issues per even / odd ring slot
     static_assert(R == 2 || R == 4 || R == 6, "ring depth");
@@ -629,12 +646,22 @@ __global__ __launch_bounds__(64 * kGramWaves, OCC) void k_cross(const T* __restr
     const int cl = lane >> 3, sj = (lane & 7) ^ (cl & 6);
     const int64_t nslabs = (nvec + kCrossSlab - 1) / kCrossSlab;
     const int64_t ngroups = (p + kCrossA - 1) / kCrossA, nsuper = (ngroups + kGramWaves - 1) / kGramWaves;
-    const int64_t my_slabs = nslabs > blockIdx.y ? (nslabs - blockIdx.y + gridDim.y - 1) / gridDim.y : 0;
+    // Which (super-group lane, row lane) this workgroup takes.  Workgroups go to the 8 XCDs round-robin by their linear id, and
+    // the gridDim.x blocks of one row lane read the SAME B sub-chunks (32 columns x their rows) at about the same time: placed
+    // on one XCD they share them through its L2 instead of each fetching them over the fabric (round 3 counted 89.8 GB fetched
+    // per 80 GB of X: the B pieces, once per 256-column super-group).  Speed only, never correctness.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.y % 8 == 0) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, j = lin >> 3;
+        bx = j % gridDim.x;
+        by = (j / gridDim.x) * 8 + xcd;
+    }
+    const int64_t my_slabs = nslabs > by ? (nslabs - by + gridDim.y - 1) / gridDim.y : 0;
     // sub-chunks this block's row lane really has: only the very last slab of the column can be partial
     int64_t nq = my_slabs * kX2SPS;
-    if (my_slabs > 0 && (int64_t)blockIdx.y + (my_slabs - 1) * gridDim.y == nslabs - 1)
+    if (my_slabs > 0 && (int64_t)by + (my_slabs - 1) * gridDim.y == nslabs - 1)
         nq -= kX2SPS - ((nvec - (nslabs - 1) * kCrossSlab) + kX2SV - 1) / kX2SV;
-    auto sub_v0 = [&](int64_t q) { return ((int64_t)blockIdx.y + (q / kX2SPS) * gridDim.y) * kCrossSlab + (q % kX2SPS) * kX2SV; };
+    auto sub_v0 = [&](int64_t q) { return ((int64_t)by + (q / kX2SPS) * gridDim.y) * kCrossSlab + (q % kX2SPS) * kX2SV; };
     const int bcol_i = 8 * wave + cl;
     const V* bsrc = reinterpret_cast<const V*>(X + bcols[bcol_i < nbc ? bcol_i : 0] * ld) + sj;
     const unsigned a_base = lds_addr_uniform(&s_a[wave][0][0]), b_base = lds_addr_uniform(&s_b[0][0]) + 1024u * (unsigned)wave,
@@ -644,7 +671,7 @@ __global__ __launch_bounds__(64 * kGramWaves, OCC) void k_cross(const T* __restr
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u) f_slot[t][u] = (16 * t + c) * kX2SV + ((4 * u + g) ^ ((16 * t + c) & 6));
-    for (int64_t sg = blockIdx.x; sg < nsuper; sg += gridDim.x) {
+    for (int64_t sg = bx; sg < nsuper; sg += gridDim.x) {
         const int64_t cg = sg * kGramWaves + wave;
         const int64_t a0 = cg * kCrossA;
         const V* asrc[8];
@@ -669,8 +696,17 @@ __global__ __launch_bounds__(64 * kGramWaves, OCC) void k_cross(const T* __restr
             }
         };
         dvec4 tile[kCrossTA * kCrossTB];
+        // fp32 storage (round 4): the products run on the fp32 matrix pipe -- v_mfma_f32_16x16x4_f32, twice the rate of the fp64
+        // instruction the widened operands took (11.1 ms per 40 GB, matrix-bound) -- into fp32 tiles that start from zero every
+        // kCrossFold sub-chunks (256 rows) and are folded into the fp64 running tiles, as k_gramstep does.  Its D fragment has
+        // rows 4 g + q where the fp64 instruction has g + 4 q: the running tiles live in that layout (the store below knows).
+        fvec4 t32[F32 ? kCrossTA * kCrossTB : 1];
 #pragma unroll
         for (int t = 0; t < kCrossTA * kCrossTB; ++t) tile[t] = dvec4{0.0, 0.0, 0.0, 0.0};
+        if constexpr (F32) {
+#pragma unroll
+            for (int t = 0; t < kCrossTA * kCrossTB; ++t) t32[t] = fvec4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int j = 0; j < R / 2; ++j)
             if (j < nq) { issue(j, 0); issue(j, 1); }
@@ -700,15 +736,16 @@ __global__ __launch_bounds__(64 * kGramWaves, OCC) void k_cross(const T* __restr
             if (q + R / 2 < nq) issue(q + R / 2, 0);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            double b[2][NV][kCrossTB];
+            using BT = std::conditional_t<F32, float, double>;    // the type the products are taken in
+            BT b[2][NV][kCrossTB];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int e = 0; e < NV; ++e)
 #pragma unroll
                     for (int gb = 0; gb < kCrossTB; ++gb) {
-                        b[u][e][gb] = (double)bf[u][gb][e];
-                        if constexpr (HASW) b[u][e][gb] *= (double)wf[u][e];
+                        b[u][e][gb] = (BT)bf[u][gb][e];
+                        if constexpr (HASW) b[u][e][gb] *= (BT)wf[u][e];
                     }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -716,10 +753,12 @@ __global__ __launch_bounds__(64 * kGramWaves, OCC) void k_cross(const T* __restr
                 for (int e = 0; e < NV; ++e)
 #pragma unroll
                     for (int ga = 0; ga < 2; ++ga) {
-                        const double a = (double)af[u][ga][e];
+                        const BT a = (BT)af[u][ga][e];
 #pragma unroll
-                        for (int gb = 0; gb < kCrossTB; ++gb)
-                            tile[ga * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u][e][gb], tile[ga * kCrossTB + gb], 0, 0, 0);
+                        for (int gb = 0; gb < kCrossTB; ++gb) {
+                            if constexpr (F32) t32[ga * kCrossTB + gb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[u][e][gb], t32[ga * kCrossTB + gb], 0, 0, 0);
+                            else tile[ga * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u][e][gb], tile[ga * kCrossTB + gb], 0, 0, 0);
+                        }
                     }
             // ---- odd half: slot 2q + 1 (younger: 2q+2, 2q+3, and 2q+4, just issued) ----------------------------------
             __builtin_amdgcn_sched_barrier(0);
@@ -745,11 +784,23 @@ __global__ __launch_bounds__(64 * kGramWaves, OCC) void k_cross(const T* __restr
                 for (int e = 0; e < NV; ++e)
 #pragma unroll
                     for (int ga = 0; ga < 2; ++ga) {
-                        const double a = (double)af[u][ga][e];
+                        const BT a = (BT)af[u][ga][e];
 #pragma unroll
-                        for (int gb = 0; gb < kCrossTB; ++gb)
-                            tile[(2 + ga) * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u][e][gb], tile[(2 + ga) * kCrossTB + gb], 0, 0, 0);
+                        for (int gb = 0; gb < kCrossTB; ++gb) {
+                            if constexpr (F32) t32[(2 + ga) * kCrossTB + gb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[u][e][gb], t32[(2 + ga) * kCrossTB + gb], 0, 0, 0);
+                            else tile[(2 + ga) * kCrossTB + gb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u][e][gb], tile[(2 + ga) * kCrossTB + gb], 0, 0, 0);
+                        }
                     }
+            if constexpr (F32) {
+                if ((q % kCrossFold) == kCrossFold - 1 || q == nq - 1) {
+#pragma unroll
+                    for (int t = 0; t < kCrossTA * kCrossTB; ++t) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) tile[t][q4] += (double)t32[t][q4];
+                        t32[t] = fvec4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -757,10 +808,10 @@ __global__ __launch_bounds__(64 * kGramWaves, OCC) void k_cross(const T* __restr
 #pragma unroll
         for (int t = 0; t < kCrossTA * kCrossTB; ++t) {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) s_red[(g + 4 * q4) * 16 + c] = tile[t][q4];   // D[i = g + 4 q4][j = c]
+            for (int q4 = 0; q4 < 4; ++q4) s_red[(F32 ? 4 * g + q4 : g + 4 * q4) * 16 + c] = tile[t][q4];   // D[i = g + 4 q4][j = c] (fp32 pipe: i = 4 g + q4)
             __builtin_amdgcn_wave_barrier();
             if (cg < ngroups) {
-                double* __restrict__ out = partials + (cg * gridDim.y + blockIdx.y) * kCrossRec + t * 256;
+                double* __restrict__ out = partials + (cg * gridDim.y + by) * kCrossRec + t * 256;
 #pragma unroll
                 for (int v = lane; v < 256; v += 64) out[v] = s_red[v];
             }

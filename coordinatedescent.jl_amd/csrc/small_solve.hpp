@@ -462,10 +462,10 @@ int32_t small_prepare(cdh_handle h) {     // buffers, X'y and diag(G) of the cur
             using T = std::remove_pointer_t<decltype(t)>;
             const dim3 grid((unsigned)c.cross_GX, (unsigned)c.cross_J), block(64 * kGramWaves);
             if (h->has_w)
-                hipLaunchKernelGGL((k_cross<T, true>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, cols, nbc,
+                hipLaunchKernelGGL((k_cross<T, true, 2, 2, cross_occ<T>()>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, cols, nbc,
                                    (const T*)h->w, c.d_cross_part);
             else
-                hipLaunchKernelGGL((k_cross<T, false>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, cols, nbc,
+                hipLaunchKernelGGL((k_cross<T, false, 2, 2, cross_occ<T>()>), grid, block, 0, h->stream, (const T*)h->X, h->ld, h->nvec, h->p, cols, nbc,
                                    (const T*)nullptr, c.d_cross_part);
             return CDH_OK;
         }));

@@ -239,6 +239,12 @@ int32_t cdh_device_loop_stats(cdh_handle h, int64_t *out12);
  * -- the quantity the certificates' relative margin (1e-9 for fp64 storage) has to cover.
  * out3 = {drift at the last re-reference, the largest seen on this handle, re-references measured}. */
 int32_t cdh_cache_drift(cdh_handle h, int32_t rereference_now, double *out3);
+/* Inspection: the Gram column X'X_k (X'WX_k) the cache holds for coordinate k1 (1-based; CDH_BAD_ARG if it holds none),
+ * p doubles, and the relative error its entries are DECLARED to carry, in units of sqrt(a_i a_k): 0 for fp64 storage; for
+ * fp32 storage 2^-24 * 512 / sqrt(n_total) -- the fp32 matrix pipe sums 256-row chunks in fp32 before folding them into
+ * fp64 -- which the certificates of the skipped visits allow for (no reference counterpart: the reference reads X itself at
+ * every visit, cd_differentiable_function.jl:94-99). */
+int32_t cdh_cache_gram_column(cdh_handle h, int64_t k1, double *out_p, double *out_eps);
 /* Problems whose Gram matrix fits on chip -- p <= 1024 columns, one process -- are solved in ONE launch.  With at most
  * 16 MB of X (the reference's own test and benchmark shapes: test/lasso.jl:76-101, benchmark/cd_bench.jl:8-14) from the
  * first solve; with more, once the solves the handle ran on the streamed kernels have cost what building the matrix

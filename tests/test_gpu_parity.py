@@ -1051,6 +1051,37 @@ def test_gradient_cache_serves_fp32_storage():
     np.testing.assert_allclose(out[3][3], Y - X @ out[3][0][-1], rtol=0, atol=2e-3)    # the caught-up residual
 
 
+@pytest.mark.parametrize("n", [3000, 200_000])
+def test_fp32_gram_columns_carry_the_declared_error(n):
+    """fp32 storage: k_cross takes the products on the fp32 matrix pipe (256-row partial sums in fp32, folded into fp64:
+    round 4).  The Gram columns the cache holds are compared with fp64 sums of the SAME fp32 data: the error of an entry,
+    in units of sqrt(a_i a_j), must stay under what cdh_cache_gram_column declares (2^-24 * 512 / sqrt(n)) -- the term the
+    certificates of skipped visits allow for.  Includes a pair of fully correlated columns (the worst case of the bound)."""
+    rng = np.random.default_rng(64)
+    p = 96
+    X = rng.standard_normal((n, p))
+    X[:, 5] = X[:, 4] * 1.5                      # fully correlated: every chunk's partial sum has the same sign
+    X = np.asfortranarray(X.astype(np.float32))
+    Y = (X[:, :6].astype(np.float64) @ rng.standard_normal(6) + rng.standard_normal(n)).astype(np.float32)
+    f = cd.CDLeastSquaresLoss(Y, X)
+    f.set_gradient_cache(3)
+    f.set_onchip_solve(False)
+    x = cd.SparseIterate(p)
+    cd.coordinateDescent_(x, f, cd.ProxL1(0.05), cd.CDOptions(maxIter=50, optTol=1e-6, randomize=False))
+    assert f.cache_stats()["gram_columns"] >= x.nnz > 0
+    X64 = X.astype(np.float64)
+    a = np.einsum("ij,ij->j", X64, X64)
+    worst, checked = 0.0, 0
+    for k in x.nzval2ind.tolist():
+        col, eps = f.cache_gram_column(k)
+        exact = X64.T @ X64[:, k - 1]
+        err = np.max(np.abs(col - exact) / np.sqrt(a * a[k - 1]))
+        assert err <= eps, (n, k, err, eps)
+        worst, checked = max(worst, err), checked + 1
+    assert checked > 0 and eps == pytest.approx(2.0 ** -24 * 512 / np.sqrt(n))
+    f.close()
+
+
 def test_gradient_cache_keeps_g_on_the_device_and_reports_its_drift():
     """Whole full passes run on the device (scan -> covariance-form blocks with the certificate re-check in the g
     update): the stats say so, the iterates are the oracle's, and cdh_cache_drift -- which takes the carried gradient

@@ -94,7 +94,7 @@ template <typename T> int run(int64_t n, int64_t p, int reps) {
                 scale = std::max(scale, std::fabs(ref[at]));
             }
         printf("   %-30s max |diff| %.3e  (largest entry %.3e)%s\n", name, worst, scale, weighted ? "  [weighted]" : "");
-        return worst <= 1e-9 * scale;
+        return worst <= (sizeof(T) == 4 ? 2e-6 : 1e-9) * scale;   // fp32 storage: the product kernel sums 256-row chunks in fp32 (round 4)
     };
     bool ok = true;
     for (int nbc : {32, 16, 5}) {
@@ -111,6 +111,11 @@ template <typename T> int run(int64_t n, int64_t p, int reps) {
         ok = compare("k_cross R=4 occ2 nt vs round 2", out0, out1, nbc, false) && ok;
         timeit("k_cross PRODUCT (R=2 occ3 nt prio)", [&] {
             hipLaunchKernelGGL((k_cross<T, false>), dim3(GX, J3), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part3); }, out1, nbc);
+        if (sizeof(T) == 4) {
+            const int J2 = (int)std::max<int64_t>(1, std::min<int64_t>(nslabs, ((int64_t)cross_occ<T>() * cus) / GX));
+            timeit("k_cross PRODUCT f32 (fp32 pipe, occ2)", [&] {
+                hipLaunchKernelGGL((k_cross<T, false, 2, 2, cross_occ<T>()>), dim3(GX, J2), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part3); }, out1, nbc);
+        }
         timeit("k_cross2 (LDS-DMA, nt A)", [&] {
             hipLaunchKernelGGL((k_cross2<T, false, 2>), dim3(GX, J), dim3(64 * kGramWaves), 0, 0, X, ld, nvec, p, dcols, nbc, (const T*)nullptr, part); }, out1, nbc);
         ok = compare("k_cross2 nt vs k_cross", out0, out1, nbc, false) && ok;
