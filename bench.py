@@ -205,6 +205,25 @@ def cfg1_cpu_vs_gpu(device=0):
     t_gpu = (time.perf_counter() - t0) / reps
     passes, visits = f.last_stats["passes"], f.last_stats["visits"]
     onchip, last = f.onchip_stats(), f.onchip_last()
+    # the reference's DEFAULT visit order is shuffled (CDOptions.randomize = true, src/utils.jl:18): the same solve with seeded
+    # shuffled sweeps on both sides (the documented splitmix64 substitute for Julia's global RNG), same bar
+    osh = dict(o, randomize=True, seed=7)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        xso = O.SparseIterate(p)
+        sts = O.coordinateDescent_(xso, fo, O.ProxL1(lam), O.CDOptions(**osh))
+    t_cpu_sh = (time.perf_counter() - t0) / reps
+    xs = cd.SparseIterate(p)
+    cd.coordinateDescent_(xs, f, cd.ProxL1(lam), cd.CDOptions(**osh))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        xs = cd.SparseIterate(p)
+        cd.coordinateDescent_(xs, f, cd.ProxL1(lam), cd.CDOptions(**osh))
+    t_gpu_sh = (time.perf_counter() - t0) / reps
+    shuffled = {"cpu_port_ms": t_cpu_sh * 1e3, "gpu_ms": t_gpu_sh * 1e3, "passes": f.last_stats["passes"], "cpu_passes": sts["passes"],
+                "visits": f.last_stats["visits"], "max_abs_beta_diff": float(np.max(np.abs(xs.dense() - xso.dense()))),
+                "same_support_order": bool(xs.nzval2ind.tolist() == xso.nzval2ind.tolist()),
+                "solve_kernel_us": f.onchip_last()["kernel_us"]}
     f.close()
     return {"workload": "lasso_n1000_p200_s10_lambda0.1_full_solve", "cpu_port_ms": t_cpu * 1e3, "cpu_cores": 1,
             "gpu_ms": t_gpu * 1e3, "gpu_ms_incl_upload_and_create": (t_gpu + t_up) * 1e3,
@@ -214,7 +233,7 @@ def cfg1_cpu_vs_gpu(device=0):
             # the GPU side is ONE launch per solve (csrc/small_solve.hpp): how many solves took it, and of the last one the
             # kernel's own time, its visit steps and the clock the chip held for a one-wave kernel
             "one_launch_solves": onchip["solves"], "solve_kernel_us": last["kernel_us"], "solve_kernel_steps": last["steps"],
-            "solve_kernel_clock_GHz": last["clock_GHz"]}
+            "solve_kernel_clock_GHz": last["clock_GHz"], "shuffled_sweeps": shuffled}
 
 
 def cfg3_path(device=0, n=2_000_000, p=5000, nlam=100):

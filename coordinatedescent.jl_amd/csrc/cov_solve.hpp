@@ -33,7 +33,7 @@
 constexpr int kCsThreads = 256;          // 4 waves, one per SIMD: gram_scalar_body<4> holds a 64-entry Gram column per lane (128 VGPRs) next to the loops' state
 constexpr int kCsWaves = kCsThreads / 64;
 constexpr int kCsNearMax = 96;           // inactive coordinates failing the bound beyond which the kernel folds and scans again
-constexpr int64_t kCsShuffleMaxP = 12288;   // the shuffle's two p-sized int arrays must fit LDS
+constexpr int64_t kCsShuffleMaxP = 5120;    // the shuffle's six (p + 1)-sized int arrays must fit LDS (under the smallest tracked Gram block)
 constexpr size_t kCsLdsBudget = (size_t)134 * 1024;   // dynamic LDS next to ~24 KB of static arrays (160 KB per CU)
 constexpr int kCsTrackedMargin = 24;     // room in the tracked list for entering and near-threshold coordinates next to the support
 constexpr int kCsUcapMax = 124;          // tracked coordinates whose Gram block is kept in LDS (124 x 124 doubles = 120 KB)
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     using R = GramRec<4>;
     constexpr int B = R::B;
     constexpr int E = kCsE;
-    extern __shared__ double s_dynamic[];        // [G_UU: ucap x ucap doubles][tracked arrays: 84 ucap bytes][randomize: order[p], draw[p] int32]
+    extern __shared__ double s_dynamic[];        // [G_UU: ucap x ucap doubles; a shuffle's scratch overlays it][tracked arrays: 84 ucap bytes]
     __shared__ double s_rec[R::N];
     __shared__ int s_mu[B];
     __shared__ double s_h[B];
@@ -149,8 +149,6 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         lt.nv = d; d += ucap; lt.qs = d; d += ucap; lt.tv = d; d += ucap;
         lt.tch = reinterpret_cast<int32_t*>(d);
     }
-    int32_t* s_order = lt.tch + ((ucap + 1) & ~1);
-    int32_t* s_draw = s_order + p;
     const CsTracked gt{b.uk, b.voff, b.iota, b.ubeta, b.uom, b.ugx, b.hs, b.newval, b.qs, b.tv, b.touched};   // ... and the global one
 
     for (int64_t k = tid; k < p; k += kCsThreads) { b.i2s[k] = 0; b.bfold[k] = b.beta[k]; b.inmoved[k] = 0; b.gxp[k] = -1; b.iota[k] = k; }
@@ -212,19 +210,19 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         const bool direct = full && !randomize;      // an ordered full pass visits k = i: no list
         // ---- reset!(it, full) + collect(it) (atom_iterator.jl:34-37, 53-64; the splitmix64 substitute of sparse_iterate.hpp) ----
         if (randomize) {
-            for (int i = tid; i < L; i += kCsThreads) {
-                s_order[i] = i;
-                if (i + 1 < L) {
-                    uint64_t st = rng + (uint64_t)i * 0x9E3779B97F4A7C15ull;
-                    s_draw[i] = i + (int)mod64_small(small_rng_next(st), (uint32_t)(L - i));
-                }
+            // the shuffle's six (p + 1)-sized arrays overlay the tracked Gram block in LDS, which is refilled below anyway (a
+            // shuffled pass visits its coordinates in a new order); Fisher-Yates itself without the serial swaps: small_solve.hpp
+            int32_t* f_draw = reinterpret_cast<int32_t*>(s_dynamic);
+            int32_t *f_cnt = f_draw + (p + 1), *f_off = f_cnt + (p + 1), *f_bucket = f_off + (p + 1), *f_par = f_bucket + (p + 1), *f_out = f_par + (p + 1);
+            for (int i = tid; i + 1 < L; i += kCsThreads) {
+                uint64_t st = rng + (uint64_t)i * 0x9E3779B97F4A7C15ull;
+                f_draw[i] = i + (int)mod64_small(small_rng_next(st), (uint32_t)(L - i));
             }
             if (L > 1) rng += (uint64_t)(L - 1) * 0x9E3779B97F4A7C15ull;
             __syncthreads();
-            if (tid == 0)
-                for (int i = 0; i + 1 < L; ++i) { const int j = s_draw[i]; const int t = s_order[i]; s_order[i] = s_order[j]; s_order[j] = t; }
-            __syncthreads();
-            for (int i = tid; i < L; i += kCsThreads) b.list[i] = full ? s_order[i] : b.s2i[s_order[i]];
+            parallel_fisher_yates<kCsThreads>(tid, L, f_draw, f_cnt, f_off, f_bucket, f_par, f_out, s_w, [] { __syncthreads(); });
+            for (int i = tid; i < L; i += kCsThreads) b.list[i] = full ? f_out[i] : b.s2i[f_out[i]];
+            cnt_prev = -1;
         } else if (!full) {
             for (int i = tid; i < L; i += kCsThreads) b.list[i] = b.s2i[i];
         }
@@ -703,7 +701,7 @@ int32_t cs_alloc(cdh_handle h) {
         (void)hipGetLastError();
         c.cs_lds_budget = (size_t)36 * 1024;          // what the default 64 KB leave next to the kernel's static arrays
     }
-    c.cs_shuffle_ok = 8 * p + 8 * 16 * 16 + (kCsTrackedBytes + 8) * 16 <= c.cs_lds_budget;
+    c.cs_shuffle_ok = true;
     return CDH_OK;
 }
 
@@ -733,7 +731,7 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     *outcome = kCsNotNow;
     c.prep_state = 0;
     if (!c.cs_enabled || !c.cov || !gc_applicable(h) || c.mode == 0 || h->p < kScreenMinPass || h->p > ((int64_t)1 << 26)) return CDH_OK;
-    if (o->randomize && (h->p > kCsShuffleMaxP || !c.cs_shuffle_ok)) return CDH_OK;
+    if (o->randomize && h->p > kCsShuffleMaxP) return CDH_OK;
     const bool full = *conv;
     double cert_abs = 0.0;
     if (full) {
@@ -759,7 +757,7 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     // One workgroup serves supports whose Gram block fits its LDS: beyond that every visit's update of the tracked gradients
     // is a gather through one CU (measured at benchmark/cd_bench.jl's shape, 774 non-zeros: 0.38 s against 0.11 s for the
     // pass-by-pass kernels, which spread that update over the chip) -- larger supports stay with those.
-    const size_t shuffle_bytes = o->randomize ? 8 * (size_t)h->p : 0;
+    const size_t shuffle_bytes = 0;              // (a shuffle's scratch overlays the tracked Gram block)
     int ucap = kCsUcapMax;
     {
         const size_t budget = c.cs_lds_budget ? c.cs_lds_budget : kCsLdsBudget;
@@ -799,6 +797,7 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     ucap = kCsUcapMax;
     while (ucap > 8 && 8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > c.cs_lds_budget) ucap -= 4;
     if (h->x.nnz() > ucap - kCsTrackedMargin) return CDH_OK;     // (the budget the runtime really granted is smaller)
+    if (o->randomize && 24 * ((size_t)h->p + 1) > 8 * (size_t)ucap * ucap) return CDH_OK;   // the shuffle's scratch must fit under the Gram block
     const unsigned lds = (unsigned)(8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes);
     hipLaunchKernelGGL(k_cov_solve, dim3(1), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
     HIPCHK(h, hipGetLastError());

@@ -52,15 +52,79 @@ __device__ __forceinline__ uint64_t small_rng_next(uint64_t& state) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
     } while (0)
 
+// ---- Fisher-Yates without its L serial swaps -----------------------------------------------------------------------------
+// The sequential loop `for i < L - 1: swap(order[i], order[j_i])` (j_i in [i, L), order = identity) leaves at position i what
+// position j_i held just before step i.  A position x >= t has, before step t, been written only by the steps i' < t that
+// targeted it (j_i' = x), each depositing what position i' held before step i':
+//     final[i] = w(P(i))  if  P(i) = max{ i' < i : j_i' = j_i } exists, else j_i;
+//     w(i)     = w(pred(i))  if  pred(i) = max{ i' < i : j_i' = i } exists, else i      (what position i holds before step i).
+// So: bucket the steps by target (counting sort with LDS atomics: a bucket holds ~ln L steps, in any order), read P and pred
+// off the buckets, resolve the pred chains (they strictly decrease) by pointer doubling in ceil(log2 L) rounds, and gather.
+// Same permutation as the loop, bit for bit (tests: the oracle's visit orders; tests/test_host_cpp.py's scheduler).
+// NT threads (one wave, or one workgroup) call it together; `sync` is their barrier.  All arrays in LDS: draw[L] (in: j_i for
+// i < L - 1), cnt[L], off[L + 1], bucket[L], par[L], out[L] (the permutation); s_x: NT / 64 ints.
+template <int NT, typename Sync>
+__device__ __forceinline__ int pfy_thread_prefix(int v, int tid, int* s_x, Sync sync) {     // exclusive prefix of v over the threads
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += up; }
+    if constexpr (NT > 64) {
+        if ((tid & 63) == 63) s_x[tid >> 6] = inc;
+        sync();
+        int base = 0;
+        for (int wv = 0; wv < (tid >> 6); ++wv) base += s_x[wv];
+        sync();
+        return base + inc - v;
+    }
+    return inc - v;
+}
+template <int NT, typename Sync>
+__device__ __forceinline__ void parallel_fisher_yates(int tid, int L, int32_t* draw, int32_t* cnt, int32_t* off, int32_t* bucket,
+                                                      int32_t* par, int32_t* out, int* s_x, Sync sync) {
+    for (int i = tid; i < L; i += NT) { cnt[i] = 0; if (i == L - 1) draw[i] = L - 1; }    // (the last position: a step onto itself)
+    sync();
+    for (int i = tid; i < L; i += NT) atomicAdd(&cnt[draw[i]], 1);
+    sync();
+    {
+        const int seg = (L + NT - 1) / NT, s0 = min(tid * seg, L), s1 = min(s0 + seg, L);
+        int sum = 0;
+        for (int x = s0; x < s1; ++x) sum += cnt[x];
+        int run = pfy_thread_prefix<NT>(sum, tid, s_x, sync);
+        for (int x = s0; x < s1; ++x) { const int c = cnt[x]; off[x] = run; run += c; cnt[x] = 0; }
+        if (tid == 0) off[L] = L;
+    }
+    sync();
+    for (int i = tid; i < L; i += NT) { const int x = draw[i]; const int at = atomicAdd(&cnt[x], 1); bucket[off[x] + at] = i; }
+    sync();
+    for (int i = tid; i < L; i += NT) {
+        const int x = draw[i];
+        int P = -1, pr = -1;
+        for (int e = off[x], e1 = off[x + 1]; e < e1; ++e) { const int s = bucket[e]; if (s < i && s > P) P = s; }
+        for (int e = off[i], e1 = off[i + 1]; e < e1; ++e) { const int s = bucket[e]; if (s < i && s > pr) pr = s; }
+        out[i] = P;
+        par[i] = pr >= 0 ? pr : i;
+    }
+    sync();
+    int32_t *cur = par, *nxt = cnt;                  // pointer doubling, double-buffered (cnt is free by now)
+    for (int span = 1; span < L; span <<= 1) {
+        for (int i = tid; i < L; i += NT) nxt[i] = cur[cur[i]];
+        sync();
+        int32_t* t = cur; cur = nxt; nxt = t;
+    }
+    for (int i = tid; i < L; i += NT) { const int P = out[i]; out[i] = P >= 0 ? cur[P] : draw[i]; }
+    sync();
+}
+
 // reset!(it, full) + collect(it) (atom_iterator.jl:34-37, 53-64): list[0 .. L) = the pass's visit list.  Shuffled:
 // Fisher-Yates, j_i = i + next() mod (L - i); splitmix64's state is a counter -- draw i is a function of state + (i + 1)
-// gamma alone -- so the draws are made by all lanes and only the swaps are sequential.  `draw` may alias `list`.
+// gamma alone -- so the draws are made by all lanes, and the permutation they define is assembled by all lanes too
+// (parallel_fisher_yates above).
 __device__ __forceinline__ int wave_build_list(int lane, bool full, int randomize, int p, int nnz, uint64_t& rng, int32_t* order,
-                                               int32_t* draw, int32_t* list, const int32_t* slot2ind) {
+                                               int32_t* draw, int32_t* list, const int32_t* slot2ind, int32_t* fy_off, int32_t* fy_bucket,
+                                               int32_t* fy_par) {
     const int L = full ? p : nnz;
     if (randomize) {
         for (int i = lane; i < L; i += 64) {
-            order[i] = i;
             if (i + 1 < L) {
                 uint64_t st = rng + (uint64_t)i * 0x9E3779B97F4A7C15ull;
                 draw[i] = i + (int)mod64_small(small_rng_next(st), (uint32_t)(L - i));
@@ -68,13 +132,9 @@ __device__ __forceinline__ int wave_build_list(int lane, bool full, int randomiz
         }
         if (L > 1) rng += (uint64_t)(L - 1) * 0x9E3779B97F4A7C15ull;
         CDH_WAVE_SYNC();
-        if (lane == 0)
-            for (int i = 0; i + 1 < L; ++i) {
-                const int j = draw[i];
-                const int t = order[i]; order[i] = order[j]; order[j] = t;
-            }
-        CDH_WAVE_SYNC();
-        for (int i0 = 0; i0 < L; i0 += 64) {                  // (read everything of a group before `list`, which may be `draw`, is written)
+        // (round 3 ran the L - 1 swaps on lane 0: a third of a shuffled cfg1 solve; `list` serves as the scratch counter array)
+        parallel_fisher_yates<64>(lane, L, draw, list, fy_off, fy_bucket, fy_par, order, (int*)nullptr, [] { CDH_WAVE_SYNC(); });
+        for (int i0 = 0; i0 < L; i0 += 64) {
             const int i = i0 + lane;
             const int v = i < L ? (full ? order[i] : slot2ind[order[i]]) : 0;
             if (i < L) list[i] = v;
@@ -152,6 +212,9 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
     int32_t* s_order = s_ind2slot + p;                           // the shuffle; between passes: scratch of dropzeros!
     int32_t* s_draw = s_order + p;
     int32_t* s_colslot = s_draw + p;                             // coordinate -> cached column, -1 = none
+    int32_t* s_fyoff = s_colslot + p;                            // the shuffle's buckets (p + 1), their contents, the chain pointers
+    int32_t* s_fybucket = s_fyoff + p + 1;
+    int32_t* s_fypar = s_fybucket + p;
     const int lane = threadIdx.x;
     const unsigned long long below = (1ull << lane) - 1ull;
     const int has_omega = ctl->has_omega, randomize = ctl->randomize, nlam = ctl->nlam;
@@ -205,7 +268,7 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
         for (int64_t iter = 0; iter < maxIter; ++iter) {
             const bool full = conv;
             const int L = full ? p : nnz;
-            (void)wave_build_list(lane, full, randomize, p, nnz, rng, s_order, s_draw, s_list, s_slot2ind);
+            (void)wave_build_list(lane, full, randomize, p, nnz, rng, s_order, s_draw, s_list, s_slot2ind, s_fyoff, s_fybucket, s_fypar);
             // ---- _cdPass! (coordinate_descent.jl:94-110), 64 positions of the visit list at a time: lane l owns position
             // c0 + l for the whole chunk and keeps its coordinate's a, omega, beta, slot links AND gradient in registers.
             // A step evaluates every lane's visit against its current g, takes the first lane (from `done` on) that
@@ -421,7 +484,7 @@ int32_t small_prepare(cdh_handle h) {     // buffers, X'y and diag(G) of the cur
         sp.d_beta = reinterpret_cast<double*>(sp.d_io + small_beta_off(h->p)); sp.h_beta = reinterpret_cast<double*>(sp.h_io + small_beta_off(h->p));
         // dynamic LDS of the solve kernel: the p-sized state, then as many Gram columns as the rest of the CU's LDS holds
         // (the whole 160 KB when the runtime grants it, else what fits the default 64 KB)
-        const size_t state = (size_t)h->p * (4 * sizeof(double) + 6 * sizeof(int32_t));
+        const size_t state = (size_t)h->p * (4 * sizeof(double) + 9 * sizeof(int32_t)) + 2 * sizeof(int32_t);
         size_t budget = (size_t)160 * 1024;
         auto widen = [&](auto kernel) {
             return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget) == hipSuccess;
