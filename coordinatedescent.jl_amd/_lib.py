@@ -128,6 +128,8 @@ def lib():
         "cdh_col_rms": [vp, vp],
         "cdh_xt_r": [vp, vp],
         "cdh_gram": [vp, i64, vp, vp, vp, P(f64)],
+        "cdh_xt_r_cols": [vp, i64, vp, vp],
+        "cdh_resid_std": [vp, P(f64), P(f64)],
         "cdh_set_reuse_residual": [vp, i32],
         "cdh_resid_moments": [vp, P(f64), P(f64)],
         "cdh_objective": [vp, P(f64)],

@@ -624,11 +624,27 @@ class LassoSolution:
 
 
 def _std_resid(f):
-    """std(f.r): mean-removed, Bessel-corrected, from device-side moments."""
-    s, ss = C.c_double(), C.c_double()
-    check(f._L.cdh_resid_moments(f._h, C.byref(s), C.byref(ss)), f._h)
-    n = f.n_total
-    return float(np.sqrt(max(ss.value - s.value * s.value / n, 0.0) / (n - 1)))
+    """std(f.r) as Statistics.std computes it: the mean, then the centred sum of squares (two passes on the device),
+    Bessel-corrected (cdh_resid_std)."""
+    out = C.c_double()
+    check(f._L.cdh_resid_std(f._h, C.byref(out), None), f._h)
+    return float(out.value)
+
+
+def solve_screening_ols(G, c, xt_r_of, refinements=2):
+    """Xs \\ y (src/utils.jl:70; a QR in the reference) from the Gram block G = Xs'Xs and c = Xs'y: the minimum-norm solution
+    of the normal equations through the symmetric eigendecomposition of G (directions whose eigenvalue is below 1e-13 of the
+    largest are left out, as a rank-revealing QR leaves them out), then refined against the normal equations' own residual
+    Xs'(y - Xs b), which `xt_r_of(b)` evaluates on the device -- so that near-collinear screening columns do not cost the
+    squared condition number in the fitted values."""
+    w, V = np.linalg.eigh(G)
+    keep = w > 1e-13 * max(w[-1], 0.0)
+    Vk = V[:, keep]
+    pinv = (Vk / w[keep]) @ Vk.T
+    b = pinv @ c
+    for _ in range(refinements):
+        b = b + pinv @ xt_r_of(b)
+    return b
 
 
 def _as_loss(cls, X, y):
@@ -671,12 +687,19 @@ def _find_init_sigma(f, s):
     xty = np.abs(out)
     thr = np.sort(xty)[::-1][s - 1]
     S = np.nonzero(xty >= thr)[0]            # `storage .>= nlargest(s, storage)[end]`: ties kept
-    if len(S) > 64:
-        raise ArgumentError("screening set larger than 64 columns")
+    if len(S) > 4096:
+        raise ArgumentError("screening set larger than 4096 columns")
     idx1 = np.ascontiguousarray(S + 1, dtype=np.int64)
     G, c = np.zeros((len(S), len(S))), np.zeros(len(S))
     check(L.cdh_gram(f._h, len(S), _vp(idx1), _vp(G), _vp(c), None), f._h)
-    coef = np.linalg.solve(G, c)             # Xs \ y through the normal equations
+
+    def normal_residual(b):                  # Xs'(y - Xs b): initialize! forms the residual, one pass over the s columns dots it
+        check(L.cdh_initialize(f._h, f.p, len(S), _vp(idx1), _vp(np.ascontiguousarray(b))), f._h)
+        out = np.zeros(len(S))
+        check(L.cdh_xt_r_cols(f._h, len(S), _vp(idx1), _vp(out)), f._h)
+        return out
+
+    coef = solve_screening_ols(G, c, normal_residual)      # Xs \ y
     check(L.cdh_initialize(f._h, f.p, len(S), _vp(idx1), _vp(np.ascontiguousarray(coef))), f._h)
     sigma = _std_resid(f)                    # std(y - Xs * (Xs \ y))
     f._synced = None

@@ -130,6 +130,7 @@ struct GradCache {
     int64_t refresh_after = 0;      // ... after which it is (kGcCovRefresh; env CDH_GC_REFRESH for tests)
     std::vector<double> g_new;      // g as a covariance-form chunk left it, until the chunk is accepted
     double q = 0.0;                 // r'r of the (virtual) residual g describes: sqrt-lasso thresholds and updates
+    double q_exact = 0.0;           // ... as last summed from r itself (the carried value is refreshed once it has fallen far below it)
     bool q_valid = false;
     int64_t n_rollbacks = 0;
     double drift_last = 0.0, drift_max = 0.0;   // max_k |g_carried - X'r| / thr_k at the re-references so far
@@ -173,7 +174,7 @@ struct SmallCtl {
     int64_t passes, full_passes, visits;
     int32_t converged, domain_error;
     double maxH;
-    int32_t nnz, pad1;
+    int32_t nnz, precision_lost;
     int64_t steps;               // visit steps taken (each settles a run of positions and makes at most one move)
     uint64_t cycles, ticks;      // shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) the kernel ran for
 };
@@ -192,7 +193,7 @@ struct SmallPath {
     SmallCtl *d_ctl = nullptr, *h_ctl = nullptr;   // views into d_io / h_io (pinned)
     int32_t *d_sup = nullptr, *h_sup = nullptr;
     double *d_beta = nullptr, *h_beta = nullptr;
-    int64_t n_solves = 0, n_gram = 0;
+    int64_t n_solves = 0, n_gram = 0, n_precision = 0;
     bool c_valid = false;            // d_ca / h_c / yy hold X'y (X'Wy), diag(G) and y'y of the current y
     double* d_ca = nullptr;          // interleaved (c_k, a_k), then y'y at [2p]
     std::vector<double> h_c;         // host copy of c (lambda_max of a cold start needs no device work)
@@ -517,13 +518,13 @@ int32_t col_dots(cdh_handle h, int64_t j0, int64_t nc, const void* rvec, bool us
     return CDH_OK;
 }
 
-int32_t resid_moments_dev(cdh_handle h, const void* vec = nullptr) {  // -> d_red[0..2] = sum v, sum v^2, sum w v^2 (v = r unless given)
+int32_t resid_moments_dev(cdh_handle h, const void* vec = nullptr, double shift = 0.0) {  // -> d_red[0..2] = sum v, sum v^2, sum w v^2 (v = r unless given; minus shift)
     if (!vec) { CHK(sync_r(h)); vec = h->r; }
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (h->nvec + kBlock - 1) / kBlock));
     CHK(dispatch(h, [&](auto* t) {
         using T = std::remove_pointer_t<decltype(t)>;
         hipLaunchKernelGGL(k_resid_moments<T>, dim3(grid), dim3(kBlock), 0, h->stream, h->nvec,
-                           (const T*)vec, h->has_w ? (const T*)h->w : (const T*)nullptr, h->d_partials);
+                           (const T*)vec, h->has_w ? (const T*)h->w : (const T*)nullptr, h->d_partials, shift, h->n);
         return CDH_OK;
     }));
     hipLaunchKernelGGL(k_sum_records, dim3(1), dim3(kBlock), 0, h->stream, h->d_partials, grid, h->d_red);
@@ -1595,8 +1596,11 @@ static int32_t cdh_solve_impl(cdh_handle h, const cdh_options* opt, cdh_stats* o
             uint64_t rng = opt->seed;
             const double lam = h->ctrl.lambda0;
             int32_t rcs = small_solve(h, opt, &lam, 1, &rng, &st, false);
-            if (out) *out = st;
-            return rcs;
+            if (rcs != kSmallPrecisionLost) {
+                if (out) *out = st;
+                return rcs;
+            }
+            st = cdh_stats{};            // (r'r out of digits: the streamed kernels below take the call)
         }
     }
     cdh::VisitScheduler sched(h->p, opt->randomize != 0, opt->seed);
@@ -1619,18 +1623,16 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
     if (small) { CHK(small_prepare(h)); small = h->small.enabled; }
     const SmallRent rent(h, opt);
     uint64_t rng = opt->seed;       // the one-launch solve carries the scheduler's generator state itself
-    if (opt->warmStart && small) {
+    // ---- in one launch (small_solve.hpp) where the Gram form applies -- unless its r'r runs out of digits (kSmallPrecisionLost:
+    // nothing of the launch is used), in which case the streamed kernels below take the call ----
+    if (small && opt->warmStart) {
         // initialize!(f, x) (:21) makes r = y - X x by definition: the one-launch solve derives its gradient from that
         // identity (g = X'y - G x) and leaves the residual to be formed when somebody reads it
         const double lam = h->ctrl.lambda0;
         rc = small_solve(h, opt, &lam, 1, &rng, &st, true);
-    } else if (opt->warmStart) {
-        // initialize!(f, x) (:21).  Optional shortcut for warm-started paths (LassoPath): the
-        // carried residual already equals y - X beta, so the rebuild only re-rounds it.
-        if (!(h->reuse_residual && h->r_consistent)) CHK(rebuild_residual(h));
-        rc = solve(h, opt, sched, &st);
     } else if (small) {
         const double target = h->ctrl.lambda0;
+        const cdh::SupportList x_before = h->x;
         h->x.clear();                                   // fill!(x, 0)           (:25)
         HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
         // _findLambdaMax (:29) at r = y: max_k |X_k'y| / n / omega_k (sqrt-lasso: / ||y||) -- from the cached X'y
@@ -1649,6 +1651,16 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
         std::vector<double> grid((size_t)opt->numSteps + 1);   // the numSteps + 1 solves of (:32-36) inside one launch
         for (int64_t j = 0; j <= opt->numSteps; ++j) grid[(size_t)j] = std::exp((j == opt->numSteps) ? l2 : l1 + (double)j * step);
         rc = small_solve(h, opt, grid.data(), (int)grid.size(), &rng, &st, true);
+        (void)x_before;
+    }
+    if (small && rc == kSmallPrecisionLost) { small = false; st = cdh_stats{}; rc = CDH_OK; }
+    if (small) {
+        // done above
+    } else if (opt->warmStart) {
+        // initialize!(f, x) (:21).  Optional shortcut for warm-started paths (LassoPath): the
+        // carried residual already equals y - X beta, so the rebuild only re-rounds it.
+        if (!(h->reuse_residual && h->r_consistent)) CHK(rebuild_residual(h));
+        rc = solve(h, opt, sched, &st);
     } else {
         const double target = h->ctrl.lambda0;          // g itself is never mutated by the reference:
         rc = [&]() -> int32_t {                         // whatever happens below, lambda0 is put back
@@ -1733,41 +1745,118 @@ static int32_t cdh_xt_r_impl(cdh_handle h, double* out_p) {
     return CDH_OK;
 }
 
-static int32_t cdh_gram_impl(cdh_handle h, int64_t m, const int64_t* idx1, double* out_G, double* out_c, double* out_q) {
-    if (m < 1 || m > 64) return fail(h, CDH_BAD_ARG, "need 1 <= m <= 64 columns");
-    NEED_P(h, idx1);
-    NEED_P(h, out_G);
-    for (int64_t i = 0; i < m; ++i)
-        if (idx1[i] < 1 || idx1[i] > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
-    HIPCHK(h, hipSetDevice(h->device));
-    CHK(sync_r(h));
-    for (int64_t i = 0; i < m; ++i) h->h_idx[i] = idx1[i] - 1;
+// one launch of the wide-block Gram kernel over up to 64 columns (0-based, in h->h_idx[0 .. m)): rec <- (G, c = X_S'r, q = r'r)
+static int32_t gram_launch(cdh_handle h, int m, std::vector<double>& rec) {
+    using R = GramRec<4>;
     HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
     // one k_gramstep launch with no pending update: r is only read
     const int G = NGgrid(h, 4);
-    using R = GramRec<4>;
     if ((size_t)G * R::N > h->partials_doubles) return fail(h, CDH_BAD_ARG, "partial buffer too small for this grid");
     CHK(dispatch(h, [&](auto* t) {
         using T = std::remove_pointer_t<decltype(t)>;
         hipLaunchKernelGGL((k_gramstep<T, 4, true>), dim3(G), dim3(64 * kGramWaves), 0, h->stream,
-                           (const T*)h->X, h->ld, h->nvec, (const T*)nullptr, (T*)h->r, h->d_idx, h->d_hs, 0, (int)m, 0,
+                           (const T*)h->X, h->ld, h->nvec, (const T*)nullptr, (T*)h->r, h->d_idx, h->d_hs, 0, m, 0,
                            h->d_partials);
         return CDH_OK;
     }));
     hipLaunchKernelGGL(k_gram_reduce, dim3((R::N + kReduceVals - 1) / kReduceVals), dim3(64 * kReduceWaves), 0, h->stream, h->d_partials, G, R::N, h->d_red);
     HIPCHK(h, hipGetLastError());
     CHK(allreduce(h, h->d_red, R::N));
-    std::vector<double> rec((size_t)R::N);
+    rec.resize((size_t)R::N);
     HIPCHK(h, hipMemcpyAsync(rec.data(), h->d_red, sizeof(double) * R::N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int64_t i = 0; i < m; ++i) {
-        for (int64_t j = 0; j < m; ++j) {
-            const int s = (int)std::min(i, j), l = (int)std::max(i, j);
-            out_G[i * m + j] = rec[(size_t)R::g(s, l)];
+    return CDH_OK;
+}
+constexpr int64_t kGramMaxCols = 4096;
+static int32_t cdh_gram_impl(cdh_handle h, int64_t m, const int64_t* idx1, double* out_G, double* out_c, double* out_q) {
+    if (m < 1 || m > kGramMaxCols) return fail(h, CDH_BAD_ARG, "need 1 <= m <= 4096 columns");
+    NEED_P(h, idx1);
+    NEED_P(h, out_G);
+    for (int64_t i = 0; i < m; ++i)
+        if (idx1[i] < 1 || idx1[i] > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    CHK(sync_r(h));
+    using R = GramRec<4>;
+    std::vector<double> rec;
+    if (m <= 64) {
+        for (int64_t i = 0; i < m; ++i) h->h_idx[i] = idx1[i] - 1;
+        CHK(gram_launch(h, (int)m, rec));
+        for (int64_t i = 0; i < m; ++i) {
+            for (int64_t j = 0; j < m; ++j) {
+                const int s = (int)std::min(i, j), l = (int)std::max(i, j);
+                out_G[i * m + j] = rec[(size_t)R::g(s, l)];
+            }
+            if (out_c) out_c[i] = rec[(size_t)(R::OFF_C + i)];
         }
-        if (out_c) out_c[i] = rec[(size_t)(R::OFF_C + i)];
+        if (out_q) *out_q = rec[(size_t)R::OFF_Q];
+        return CDH_OK;
     }
-    if (out_q) *out_q = rec[(size_t)R::OFF_Q];
+    // More than one launch's worth (round 4; _findInitResiduals! takes any s, src/utils.jl:65-77): groups of 32 columns, one
+    // launch per PAIR of groups -- the 64 columns of a pair give the pair's two diagonal blocks and the block between them.
+    const int64_t ng = (m + 31) / 32;
+    for (int64_t a = 0; a < ng; ++a)
+        for (int64_t b = a + 1; b < ng; ++b) {
+            const int64_t a0 = 32 * a, a1 = std::min<int64_t>(a0 + 32, m), b0 = 32 * b, b1 = std::min<int64_t>(b0 + 32, m);
+            const int na = (int)(a1 - a0), nb = (int)(b1 - b0);
+            for (int i = 0; i < na; ++i) h->h_idx[i] = idx1[a0 + i] - 1;
+            for (int i = 0; i < nb; ++i) h->h_idx[na + i] = idx1[b0 + i] - 1;
+            CHK(gram_launch(h, na + nb, rec));
+            // column -> position inside the launch; every block and dot the launch holds is written (a diagonal block comes out
+            // of every pair its group is in, each time from the same sums over the same rows)
+            auto col_of = [&](int pos) { return pos < na ? a0 + pos : b0 + (pos - na); };
+            for (int pi = 0; pi < na + nb; ++pi) {
+                const int64_t i = col_of(pi);
+                for (int pj = 0; pj < na + nb; ++pj)
+                    out_G[i * m + col_of(pj)] = rec[(size_t)R::g(std::min(pi, pj), std::max(pi, pj))];
+                if (out_c) out_c[i] = rec[(size_t)(R::OFF_C + pi)];
+            }
+            if (out_q) *out_q = rec[(size_t)R::OFF_Q];
+        }
+    return CDH_OK;
+}
+
+// X_S'r (X_S'Wr for the weighted loss) for a list of columns: the refinement step of the screening init reads the normal
+// equations' residual off it (src/utils.jl:65-77 solves Xs \ y by QR; here: the Gram block plus refinement)
+static int32_t cdh_xt_r_cols_impl(cdh_handle h, int64_t m, const int64_t* idx1, double* out_m) {
+    if (m < 1 || m > h->cap) return fail(h, CDH_BAD_ARG, "need 1 <= m <= max(p, 4096) columns");
+    NEED_P(h, idx1);
+    NEED_P(h, out_m);
+    for (int64_t i = 0; i < m; ++i)
+        if (idx1[i] < 1 || idx1[i] > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<double> cd(2 * (size_t)std::min<int64_t>(m, h->p));
+    for (int64_t o = 0; o < m; o += h->p) {          // d_colout holds 2p values
+        const int64_t mm = std::min<int64_t>(h->p, m - o);
+        for (int64_t i = 0; i < mm; ++i) h->h_idx[i] = idx1[o + i] - 1;
+        HIPCHK(h, hipMemcpyAsync(h->d_idx, h->h_idx, sizeof(int64_t) * (size_t)mm, hipMemcpyHostToDevice, h->stream));
+        CHK(col_dots(h, 0, mm, h->r, h->loss == CDH_WLS, h->d_idx));
+        HIPCHK(h, hipMemcpyAsync(cd.data(), h->d_colout, sizeof(double) * 2 * (size_t)mm, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < mm; ++i) out_m[o + i] = cd[(size_t)(2 * i)];
+    }
+    return CDH_OK;
+}
+
+// std(f.r) as Statistics.std computes it (two passes: the mean, then the centred sum of squares; Bessel-corrected) --
+// lasso.jl:37,52,81,97,143 -- without the cancellation of the one-pass form when the mean is large against the spread
+static int32_t cdh_resid_std_impl(cdh_handle h, double* out_std, double* out_mean) {
+    NEED_P(h, out_std);
+    HIPCHK(h, hipSetDevice(h->device));
+    CHK(resid_moments_dev(h));
+    HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const double n = (double)h->n_total, mean = h->h_red[0] / n;
+    double ss = h->h_red[1], s1 = h->h_red[0];
+    if (mean != 0.0 && mean == mean) {
+        CHK(resid_moments_dev(h, nullptr, mean));
+        HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        s1 = h->h_red[0]; ss = h->h_red[1];         // of the centred values: s1 is rounding-sized
+    } else {
+        s1 = 0.0;
+    }
+    *out_std = std::sqrt(std::max(ss - s1 * s1 / n, 0.0) / (n - 1.0));
+    if (out_mean) *out_mean = mean;
     return CDH_OK;
 }
 
@@ -2167,6 +2256,18 @@ int32_t cdh_xt_r(cdh_handle h, double* out_p) {
 int32_t cdh_gram(cdh_handle h, int64_t m, const int64_t* idx1, double* out_G, double* out_c, double* out_q) {
     NEED_H(h);
     try { return cdh_gram_impl(h, m, idx1, out_G, out_c, out_q); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_xt_r_cols(cdh_handle h, int64_t m, const int64_t* idx1, double* out_m) {
+    NEED_H(h);
+    try { return cdh_xt_r_cols_impl(h, m, idx1, out_m); }
+    CDH_CATCH(h)
+}
+
+int32_t cdh_resid_std(cdh_handle h, double* out_std, double* out_mean) {
+    NEED_H(h);
+    try { return cdh_resid_std_impl(h, out_std, out_mean); }
     CDH_CATCH(h)
 }
 

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     const int nnz_limit = ctl->nnz_limit, busy_limit = ctl->busy_limit, inject_every = ctl->inject_every;
     uint64_t rng = ctl->rng;
     double q = ctl->q;
+    const double q_floor = ctl->q_floor;
     // 100 MHz ticks per phase (thread 0's view): list, scan, exact gradients, visits, re-check, accept, bookkeeping, dropzeros!
     uint64_t tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tmark = __builtin_amdgcn_s_memrealtime();
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         if (passes >= max_passes) { status = kCsMaxIter; break; }
         if (nnz > nnz_limit) { status = kCsOutgrown; break; }
         if (cov_visits > cov_budget) { status = kCsRefresh; break; }
+        if (sqrt_loss && q < q_floor) { status = kCsNeedQ; break; }      // r'r has run out of digits: the host sums it from r
         const bool full = conv;
         const uint64_t rng_before = rng;
         const int L = full ? (int)p : nnz;
@@ -748,6 +750,7 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
         for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return CDH_OK;
         gc_fold(h);
         if (!c.valid) return CDH_OK;
+        gc_q_guard(h);
         if (h->loss == CDH_SQRT) CHK(gc_ensure_q(h));
         CHK(gc_cert_abs(h, &cert_abs));
     }
@@ -787,7 +790,7 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
         ctl.nnz_limit = (int32_t)std::min<int64_t>({lim, support_cap, (int64_t)0x7fffffff});
     }
     ctl.busy_limit = kGcBusy; ctl.inject_every = c.inject_rollback; ctl.pad0 = ctl.pad1 = 0;
-    ctl.rng = sched.state(); ctl.q = c.q;
+    ctl.rng = sched.state(); ctl.q = c.q; ctl.q_floor = h->loss == CDH_SQRT ? kGcQGuard * c.q_exact : 0.0;
     ctl.nnz = (int32_t)h->x.nnz(); ctl.prev_conv = *prev_conv ? 1 : 0; ctl.conv = *conv ? 1 : 0; ctl.inject_count = c.inject_count;
     ctl.status = -1; ctl.n_list = 0; ctl.n_moved = 0;
     for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) c.cs_in_sup[s_] = (int32_t)h->x.coord(s_);
@@ -854,6 +857,7 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     case kCsRollback: c.n_rollbacks += 1; return CDH_OK;            // the host walks this pass the careful way
     case kCsOutgrown: return CDH_OK;                                // gc_prepare_full / gc_ready_for_cov draw the consequences
     case kCsRefresh: CHK(gc_rereference(h)); *outcome = kCsAgain; return CDH_OK;
+    case kCsNeedQ: c.q_valid = false; CHK(gc_ensure_q(h)); *outcome = kCsAgain; return CDH_OK;
     case kCsBusy:     // many inactive coordinates about to move: back off (1, 2, 4 ... 16 plain passes), as gc_pass_device does
         c.cooldown = c.backoff; c.backoff = std::min(16, 2 * c.backoff);
         gc_invalidate(h, false);

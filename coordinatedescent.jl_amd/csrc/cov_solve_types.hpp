@@ -3,11 +3,12 @@
 #pragma once
 #include <stdint.h>
 
-enum { kCsConverged = 0, kCsMaxIter = 1, kCsNeedColumns = 2, kCsRollback = 3, kCsBusy = 4, kCsRefresh = 5, kCsOutgrown = 6 };
+enum { kCsConverged = 0, kCsMaxIter = 1, kCsNeedColumns = 2, kCsRollback = 3, kCsBusy = 4, kCsRefresh = 5, kCsOutgrown = 6, kCsNeedQ = 7 };
 
 struct CovSolveCtl {
     // in
     double lambda0, n_total, optTol, cert_abs;
+    double q_floor;              // sqrt-lasso: r'r below this has run out of digits (the host sums it from r): kCsNeedQ
     int64_t max_passes;          // passes this launch may run (maxIter - those already done)
     int64_t cov_budget;          // covariance-form visits this launch may make before g is due to be re-read from X
     int32_t loss, has_omega, randomize, nnz_limit /* support size beyond which the cache stands aside */;

@@ -205,8 +205,17 @@ int32_t gc_ensure_q(cdh_handle h) {
     HIPCHK(h, hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     c.q = h->h_red[1];
+    c.q_exact = c.q;
     c.q_valid = true;
     return CDH_OK;
+}
+// The carried r'r is only good to ~1e-16 of the value its recurrence started from (q <- q - 2 h b + h^2 a, block after block,
+// pass after pass): once it has fallen to kGcQGuard of the last value summed from r itself, it is summed afresh before the
+// next pass (one pass over r, after it has caught up with the moves) -- near-noiseless problems, ||r|| << ||y||.
+constexpr double kGcQGuard = 1e-4;
+inline void gc_q_guard(cdh_handle h) {
+    GradCache& c = h->gc;
+    if (h->loss == CDH_SQRT && c.q_valid && c.q < kGcQGuard * c.q_exact) c.q_valid = false;
 }
 
 // fold what can be folded, then ask cov_ok (the active passes of a solve call this before every chunk)
@@ -222,6 +231,7 @@ bool gc_ready_for_cov(cdh_handle h, const int64_t* idx0, int64_t m) {
         for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return false;
         gc_fold(h);
     }
+    gc_q_guard(h);
     if (h->loss == CDH_SQRT && gc_ensure_q(h) != CDH_OK) return false;
     return cov_ok(h, idx0, m);
 }
@@ -728,6 +738,7 @@ int32_t gc_prepare_full(cdh_handle h, bool* go, double* cert_abs_out) {
     for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return fail(h, CDH_BAD_ARG, "gradient cache: a moved coordinate has no Gram column");
     gc_fold(h);
     if (!c.valid) return CDH_OK;      // (a device fold that failed hard leaves no gradient: the pass runs the plain way)
+    gc_q_guard(h);
     if (h->loss == CDH_SQRT) CHK(gc_ensure_q(h));
     *go = true;
     return CDH_OK;

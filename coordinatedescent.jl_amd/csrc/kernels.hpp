@@ -720,11 +720,12 @@ __global__ __launch_bounds__(64) void k_col_dots_reduce(const double* __restrict
     if (threadIdx.x == 0) { out[2 * col] = s0; out[2 * col + 1] = s1; }
 }
 
-// sum r, sum r^2 (+ sum w r^2 when w) -> partials[(block, 4)]
+// sum (r - shift), sum (r - shift)^2 (+ sum w (r - shift)^2 when w) -> partials[(block, 4)]; rows beyond n (the zero pad of
+// the last vectors) are left out when a shift is given (shift == 0: they contribute nothing anyway)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_resid_moments(int64_t nvec, const T* __restrict__ r,
                                                           const T* __restrict__ w,
-                                                          double* __restrict__ partials) {
+                                                          double* __restrict__ partials, double shift = 0.0, int64_t n = 0) {
     using V = typename VecOf<T>::V;
     constexpr int NV = VecOf<T>::N;
     __shared__ double lds[3 * (kBlock / 64)];
@@ -740,7 +741,8 @@ __global__ __launch_bounds__(kBlock) void k_resid_moments(int64_t nvec, const T*
         const T* wp = reinterpret_cast<const T*>(&wwv);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
-            const double re = (double)rp[e];
+            double re = (double)rp[e] - shift;
+            if (shift != 0.0 && j * NV + e >= n) re = 0.0;
             acc[0] += re;
             acc[1] = fma(re, re, acc[1]);
             acc[2] = fma(w ? (double)wp[e] * re : re, re, acc[2]);

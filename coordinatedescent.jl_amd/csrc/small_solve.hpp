@@ -194,6 +194,8 @@ __device__ __forceinline__ int wave_dropzeros(int lane, int nnz, const double* b
 // (A lone wave issues about one instruction per four cycles, so a step costs what it has instructions: the sqrt-lasso
 // closed form is compiled into its own kernel, and the loops over a p-vector are unrolled NP = 4 / 8 / 16 times for
 // p <= 256 / 512 / 1024 -- unrolled 16 times with a predicate per trip they alone were 1300 cycles of a step at p = 200.)
+constexpr double kSmallQGuard = 1e-6;       // r'r below this fraction of the value its recurrence started from: out of digits
+constexpr int32_t kSmallPrecisionLost = -77;   // small_solve's return code for that (not a cdh status: the callers take the streamed path)
 template <bool SQRT, int NP>
 __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int ncache, const double* __restrict__ ga,
                                                     const double* __restrict__ G, const double* __restrict__ omega,
@@ -235,6 +237,12 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
     __syncthreads();
     for (int s = lane; s < nnz; s += 64) { const int k = sup[s]; s_slot2ind[s] = k; s_ind2slot[k] = s + 1; }
     double q = SQRT ? *q_in : 0.0;
+    // The sqrt-lasso's thresholds and closed form hang on r'r, which this kernel only knows by subtraction: y'y - sum beta (c + g)
+    // at the start, q - 2 h b + h^2 a per move -- good to ~1e-16 of the value it started from, whatever is left of it.  Once r'r
+    // has fallen below kSmallQGuard of that reference (near-noiseless y: ||r|| << ||y||) the digits are gone: the kernel gives
+    // up, nothing of its work is used, and the host runs the call on the streamed kernels, which sum r'r from r itself.
+    const double q_ref = q;
+    int precision_lost = 0;
     if (g_from_c) {
         // `ga` held c = X'y (X'Wy), q_in y'y: the gradient and r'r of the iterate follow from the Gram matrix alone,
         //   g = c - G beta,   r'r = y'y - 2 beta'c + beta'G beta = y'y - sum_s beta_s (c_s + g_s)
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
             for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
             q = *q_in - acc;
             if (q < 0.0) q = 0.0;
+            if (q < kSmallQGuard * q_ref) precision_lost = 1;
         }
     }
     const uint64_t t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
     int converged = 0, dom_any = 0;
     double lastH = 0.0;
     __syncthreads();
-    for (int il = 0; il < nlam; ++il) {
+    for (int il = 0; il < nlam && !precision_lost; ++il) {
         const double lambda0 = __shfl(lam_lane, il, 64);
         bool prev_conv = false, conv = true;
         converged = 0;
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
                             __syncthreads();                                // the column is in LDS before a later step gathers from it
                         }
                     }
-                    if constexpr (SQRT) { q = q - 2.0 * h * bm + h * h * am; if (q < 0.0) q = 0.0; }
+                    if constexpr (SQRT) { q = q - 2.0 * h * bm + h * h * am; if (q < 0.0) q = 0.0; if (q < kSmallQGuard * q_ref) precision_lost = 1; }
                     done = first + 1;
                     if (done >= 64) break;
                 }
@@ -383,13 +392,14 @@ __global__ __launch_bounds__(64) void k_solve_small(SmallCtl* ctl, int p, int nc
             prev_conv = conv;
             conv = maxH < optTol;
             if (prev_conv && conv) { converged = 1; break; }
+            if (precision_lost) break;
         }
     }
     for (int k = lane; k < p; k += 64) { beta[k] = s_beta[k]; beta_out[k] = s_beta[k]; }
     for (int s = lane; s < nnz; s += 64) sup[s] = s_slot2ind[s];
     if (lane == 0) {
         ctl->rng = rng; ctl->passes = passes; ctl->full_passes = full_passes; ctl->visits = visits;
-        ctl->converged = converged; ctl->domain_error = dom_any; ctl->maxH = lastH; ctl->nnz = nnz;
+        ctl->converged = converged; ctl->domain_error = dom_any; ctl->precision_lost = precision_lost; ctl->maxH = lastH; ctl->nnz = nnz;
         ctl->steps = steps; ctl->cycles = __builtin_amdgcn_s_memtime() - t0c; ctl->ticks = __builtin_amdgcn_s_memrealtime() - t0r;
     }
 }
@@ -583,6 +593,14 @@ int32_t small_solve(cdh_handle h, const cdh_options* o, const double* lambdas, i
     HIPCHK(h, hipGetLastError());
     if (!zc) HIPCHK(h, hipMemcpyAsync(sp.h_io, sp.d_io, small_io_bytes(h->p), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ctl.precision_lost) {          // r'r ran out of digits (k_solve_small): nothing of the launch is used
+        std::vector<double> dense((size_t)h->p, 0.0);
+        for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) dense[(size_t)h->x.coord(s_)] = h->x.slot_value(s_);
+        HIPCHK(h, hipMemcpyAsync(h->beta, dense.data(), sizeof(double) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        sp.n_precision += 1;
+        return kSmallPrecisionLost;
+    }
     // what moved becomes pending residual updates (r_actual = r_virtual + X * pending: sync_r applies them before anything
     // reads r) and, for a gradient cache that holds a reference, pending moves like those of any other visit
     GradCache& c = h->gc;

@@ -171,12 +171,21 @@ int32_t cdh_col_rms(cdh_handle h, double *out_p);
 /* out_j = X_j' r for every column at the current r (At_mul_B_row for all j: the
  * screening scores of _findLargestCorrelations, utils.jl:96-106; KKT checks). */
 int32_t cdh_xt_r(cdh_handle h, double *out_p);
-/* Gram block of up to 64 columns against the current r, in one pass over them:
+/* Gram block of up to 4096 columns against the current r:
  * out_G[i*m+j] = X_i'X_j, out_c[i] = X_i'r, *out_q = r'r (all shards).  With r = y this is
- * what the s-column OLS of _findInitResiduals! needs (utils.jl:65-77: Xs \ y via the normal
- * equations), without moving any n-sized array to the host. */
+ * what the s-column OLS of _findInitResiduals! needs (utils.jl:65-77: Xs \ y), without moving
+ * any n-sized array to the host.  Up to 64 columns in one pass over them; more (round 4: the
+ * reference takes any s) in groups of 32, one launch per pair of groups. */
 int32_t cdh_gram(cdh_handle h, int64_t m, const int64_t *idx1, double *out_G, double *out_c,
                  double *out_q);
+/* out_m[i] = X_idx1[i]' r (X'Wr for the weighted loss) for a LIST of columns at the current r: one pass over those
+ * columns only.  The refinement step of the screening init: Xs \ y (utils.jl:70, a QR in the reference) is solved from the
+ * Gram block, and the normal equations' residual Xs'(y - Xs b) read off here corrects b -- so near-collinear screening
+ * columns do not cost the squared condition number. */
+int32_t cdh_xt_r_cols(cdh_handle h, int64_t m, const int64_t *idx1, double *out_m);
+/* std(f.r) as Statistics.std computes it (lasso.jl:37,52,81,97,143): two passes -- the mean, then the centred sum of
+ * squares, Bessel-corrected -- over all shards.  out_mean may be NULL. */
+int32_t cdh_resid_std(cdh_handle h, double *out_std, double *out_mean);
 /* sum r, sum r^2 over all shards (sigma of scaledLasso!, lasso.jl:134; std(f.r)). */
 int32_t cdh_resid_moments(cdh_handle h, double *out_sum, double *out_sumsq);
 /* f(beta) + lambda0 sum omega|beta| at the current state (coordinate_descent.jl:1-3). */

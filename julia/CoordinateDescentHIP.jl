@@ -26,7 +26,7 @@
 module CoordinateDescentHIP
 
 using CoordinateDescent, ProximalBase
-using LinearAlgebra: Symmetric
+using LinearAlgebra: Symmetric, eigen
 using SparseArrays: nnz
 using DataStructures: nlargest
 import CoordinateDescent: coordinateDescent!, initialize!, gradient, descendCoordinate!,
@@ -78,6 +78,12 @@ mutable struct HipMatrix{T<:Union{Float32,Float64}} <: DenseMatrix{T}
   n::Int
   p::Int
   owner::Any
+  # the iterate the handle holds, as last pushed to or pulled from it (support in slot order, values): an x that still
+  # equals it is not pushed again -- cdh_set_iterate would declare the carried residual stale for nothing, and a
+  # user-written pass over descendCoordinate! would upload p numbers per visit
+  synced_idx::Vector{Int64}
+  synced_val::Vector{Float64}
+  synced::Bool
 end
 Base.size(X::HipMatrix) = (X.n, X.p)
 Base.getindex(X::HipMatrix{T}, i::Int, j::Int) where {T} = begin
@@ -100,7 +106,7 @@ function HipMatrix(X::StridedMatrix{T}; device::Integer=0) where {T}
   h = ref[]
   GC.@preserve X check(h, ccall((:cdh_set_X_cols, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64),
                                 h, 0, p, X, stride(X, 2)))
-  M = HipMatrix{T}(h, n, p, nothing)
+  M = HipMatrix{T}(h, n, p, nothing, Int64[], Float64[], false)
   finalizer(m -> ccall((:cdh_destroy, libcdhip), Int32, (Ptr{Cvoid},), m.handle), M)
   M
 end
@@ -150,7 +156,26 @@ end
 
 numCoordinates(f::HipLoss) = f.X.p
 
+"does the handle already hold exactly this iterate (same support order, same values)?"
+function is_synced(X::HipMatrix, x::SparseIterate)
+  X.synced || return false
+  m = nnz(x)
+  m == length(X.synced_idx) || return false
+  @inbounds for i in 1:m
+    (x.nzval2ind[i] == X.synced_idx[i] && Float64(x.nzval[i]) == X.synced_val[i]) || return false
+  end
+  true
+end
+function remember_iterate!(X::HipMatrix, x::SparseIterate)
+  m = nnz(x)
+  X.synced_idx = Int64.(x.nzval2ind[1:m]); X.synced_val = Float64.(x.nzval[1:m]); X.synced = true
+  nothing
+end
+
+"x -> the handle.  `rebuild` = initialize! (r = y - X x is formed, cd_differentiable_function.jl:59-72); without it an
+iterate the handle already holds is not sent again."
 function push_iterate!(f::HipLoss, x::SparseIterate, rebuild::Bool)
+  !rebuild && is_synced(f.X, x) && return nothing
   idx = Int64.(x.nzval2ind[1:nnz(x)])
   val = Float64.(x.nzval[1:nnz(x)])
   GC.@preserve idx val begin          # ccall needs a constant symbol: one call site per entry point
@@ -161,6 +186,8 @@ function push_iterate!(f::HipLoss, x::SparseIterate, rebuild::Bool)
             f.X.handle, length(x), length(idx), idx, val)
     check(f.X.handle, st)
   end
+  f.X.synced_idx = idx; f.X.synced_val = val; f.X.synced = true
+  nothing
 end
 
 "callers read f.r afterwards (src/lasso.jl:37,134,143): one device -> host copy"
@@ -177,6 +204,7 @@ function pull_support!(f::HipLoss{T}, x::SparseIterate{T}) where {T}
   for i in 1:nz[]                       # re-insert in the library's support order
     x[idx[i]] = T(beta[idx[i]])
   end
+  remember_iterate!(f.X, x)
   x
 end
 
@@ -206,11 +234,15 @@ function gradient(f::HipLoss{T}, x::SparseIterate{T}, k::Int64) where {T}
   T(out[])
 end
 
+"""descendCoordinate!(f, g, x, k) (cd_differentiable_function.jl:83-111) on the device.  x is refreshed (p-sized); the
+residual is NOT copied back per visit -- n elements per call would be 80 MB per visit at n = 1e7 -- so inside a user-written
+pass over this operator `f.r` is stale until `pull_residual!(f)` (or `initialize!`, or `coordinateDescent!`, which end
+with one).  The reference's own `_cdPass!` (coordinate_descent.jl:102-107) never reads f.r between visits."""
 function descendCoordinate!(f::HipLoss{T}, g::ProxL1{T}, x::SparseIterate{T}, k::Int64) where {T}
   bind!(f); set_penalty!(f, g); push_iterate!(f, x, false)
   out = Ref{Float64}(0)
   check(f.X.handle, ccall((:cdh_descend, libcdhip), Int32, (Ptr{Cvoid}, Int64, Ref{Float64}), f.X.handle, k, out))
-  pull_iterate!(f, x)
+  pull_support!(f, x)
   T(out[])
 end
 
@@ -256,6 +288,7 @@ function xt_y(X::HipMatrix{T}, y::AbstractVector{T}) where {T}
   X.owner = nothing                    # whatever loss was bound has lost its y: it re-binds on its next call
   check(X.handle, ccall((:cdh_initialize, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
                         X.handle, X.p, 0, C_NULL, C_NULL))
+  X.synced = false                     # the handle's iterate is zero now, nobody's x
   out = Vector{Float64}(undef, X.p)
   check(X.handle, ccall((:cdh_xt_r, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Float64}), X.handle, out))
   out
@@ -267,20 +300,42 @@ function _findLargestCorrelations(X::HipMatrix{T}, y::AbstractVector{T}, s::Int)
   storage .>= nlargest(s, storage)[end]
 end
 
-"_findInitResiduals!(X, y, s, storage) (utils.jl:65-77): storage = y - Xs (Xs \\ y).  Xs \\ y is taken
-through the s x s normal equations, whose entries (Xs'Xs, Xs'y) come from one pass over the s columns
-(cdh_gram); the residual is formed on the device by initialize! with the coefficients as the iterate."
-function _findInitResiduals!(X::HipMatrix{T}, y::AbstractVector{T}, s::Int, storage::Vector{T}) where {T<:AbstractFloat}
-  S = _findLargestCorrelations(X, y, s)             # leaves y on the device and r = y
-  idx = Int64.(findall(S)); m = length(idx)
-  m <= 64 || throw(ArgumentError("screening set larger than 64 columns"))
+"Xs \\ y (utils.jl:70; a QR in the reference) from the Gram block G = Xs'Xs and c = Xs'y: the minimum-norm solution of the
+normal equations through the symmetric eigendecomposition of G (directions under 1e-13 of the largest eigenvalue are left
+out, as a rank-revealing QR leaves them out), refined twice against the normal equations' own residual Xs'(y - Xs b) --
+initialize! forms the residual on the device, cdh_xt_r_cols dots it with the s columns -- so that near-collinear
+screening columns do not cost the squared condition number.  Leaves r = y - Xs b on the device."
+function screening_ols!(X::HipMatrix, idx::Vector{Int64})
+  m = length(idx)
+  m <= 4096 || throw(ArgumentError("screening set larger than 4096 columns"))
   G = Matrix{Float64}(undef, m, m); c = Vector{Float64}(undef, m)
   check(X.handle, ccall((:cdh_gram, libcdhip), Int32,
                         (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                         X.handle, m, idx, G, c, C_NULL))
-  coef = Symmetric(G) \ c
+  E = eigen(Symmetric(G))
+  keep = E.values .> 1e-13 * max(E.values[end], 0.0)
+  V = E.vectors[:, keep]
+  pinvG = (V ./ E.values[keep]') * V'
+  coef = pinvG * c
+  res = Vector{Float64}(undef, m)
+  for _ in 1:2
+    check(X.handle, ccall((:cdh_initialize, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
+                          X.handle, X.p, m, idx, coef))
+    check(X.handle, ccall((:cdh_xt_r_cols, libcdhip), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}),
+                          X.handle, m, idx, res))
+    coef .+= pinvG * res
+  end
   check(X.handle, ccall((:cdh_initialize, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
                         X.handle, X.p, m, idx, coef))
+  X.synced = false                     # the handle's iterate is the OLS fit now, nobody's x
+  coef
+end
+
+"_findInitResiduals!(X, y, s, storage) (utils.jl:65-77): storage = y - Xs (Xs \\ y), any s; the residual is formed on
+the device (screening_ols!) and copied back once."
+function _findInitResiduals!(X::HipMatrix{T}, y::AbstractVector{T}, s::Int, storage::Vector{T}) where {T<:AbstractFloat}
+  S = _findLargestCorrelations(X, y, s)             # leaves y on the device and r = y
+  screening_ols!(X, Int64.(findall(S)))
   check(X.handle, ccall((:cdh_get_residual, libcdhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), X.handle, storage))
   storage
 end
@@ -294,10 +349,11 @@ function resid_moments(X::HipMatrix)
   check(X.handle, ccall((:cdh_resid_moments, libcdhip), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}), X.handle, s, ss))
   s[], ss[]
 end
-"std(f.r): mean-removed, Bessel-corrected (Statistics.std), from the two moments"
+"std(f.r) as Statistics.std computes it -- the mean, then the centred sum of squares (two passes on the device), Bessel-corrected"
 function resid_std(X::HipMatrix)
-  s, ss = resid_moments(X)
-  sqrt(max(ss - s * s / X.n, 0.0) / (X.n - 1))
+  out = Ref{Float64}(0)
+  check(X.handle, ccall((:cdh_resid_std, libcdhip), Int32, (Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}), X.handle, out, C_NULL))
+  out[]
 end
 
 function gradient_cache_mode(X::HipMatrix)
@@ -315,15 +371,7 @@ function scaledLasso!(x::SparseIterate{T}, X::HipMatrix{T}, y::AbstractVector{T}
   if options.initProcedure == :Screening
     # _findInitSigma! (utils.jl:60-64) without its copy back: scores, s x s normal equations, residual on the device
     S = _findLargestCorrelations(X, y, options.sinit)      # leaves y on the device, loss kind LS, r = y
-    idx = Int64.(findall(S)); m = length(idx)
-    m <= 64 || throw(ArgumentError("screening set larger than 64 columns"))
-    G = Matrix{Float64}(undef, m, m); c = Vector{Float64}(undef, m)
-    check(X.handle, ccall((:cdh_gram, libcdhip), Int32,
-                          (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                          X.handle, m, idx, G, c, C_NULL))
-    coef = Symmetric(G) \ c
-    check(X.handle, ccall((:cdh_initialize, libcdhip), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
-                          X.handle, X.p, m, idx, coef))
+    screening_ols!(X, Int64.(findall(S)))
     σ = T(resid_std(X))
     X.owner = f.r                     # the device holds exactly this loss's y and kind: no second upload
   elseif options.initProcedure == :InitStd

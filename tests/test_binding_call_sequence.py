@@ -136,11 +136,26 @@ def bind(f):                         # bind!(f)
         rebind(f)
 
 
+def is_synced(X, x):                 # is_synced(X, x): the handle already holds exactly this iterate
+    return getattr(X, "synced", False) and list(x.idx) == X.synced_idx and [float(v) for v in x.val] == X.synced_val
+
+
+def remember_iterate(X, x):          # remember_iterate!(X, x)
+    X.synced_idx, X.synced_val, X.synced = list(x.idx), [float(v) for v in x.val], True
+
+
+N_ITERATE_PUSHES = [0]               # cdh_set_iterate / cdh_initialize calls made by push_iterate!
+
+
 def push_iterate(f, x, rebuild):     # push_iterate!(f, x, rebuild)
+    if not rebuild and is_synced(f.X, x):
+        return
     idx = np.ascontiguousarray(x.idx, dtype=np.int64)
     val = np.ascontiguousarray(x.val, dtype=np.float64)
+    N_ITERATE_PUSHES[0] += 1
     ccall("cdh_initialize" if rebuild else "cdh_set_iterate", f.X.handle, i64(x.p), i64(len(idx)),
           ptr(idx) if len(idx) else None, ptr(val) if len(idx) else None)
+    remember_iterate(f.X, x)
 
 
 def pull_residual(f):                # pull_residual!(f)
@@ -154,6 +169,7 @@ def pull_support(f, x):              # pull_support!(f, x)
     ccall("cdh_get_beta", f.X.handle, ptr(beta))
     x.idx = idx[: nz.value].tolist()
     x.val = [float(beta[k - 1]) for k in x.idx]
+    remember_iterate(f.X, x)
     return x
 
 
@@ -211,8 +227,40 @@ def resid_moments(X):                # resid_moments(X)
 
 
 def resid_std(X):                    # resid_std(X)
-    s, ss = resid_moments(X)
-    return float(np.sqrt(max(ss - s * s / X.n, 0.0) / (X.n - 1)))
+    out = f64(0)
+    ccall("cdh_resid_std", X.handle, C.byref(out), None)
+    return out.value
+
+
+def descendCoordinate(f, lam0, omega, x, k):       # descendCoordinate!(f, g, x, k): x refreshed, f.r NOT copied back
+    bind(f)
+    set_penalty(f, lam0, omega)
+    push_iterate(f, x, False)
+    out = f64(0)
+    ccall("cdh_descend", f.X.handle, i64(k), C.byref(out))
+    pull_support(f, x)
+    return out.value
+
+
+def screening_ols(X, idx):           # screening_ols!(X, idx)
+    m = len(idx)
+    if m > 4096:
+        raise ArgumentError("screening set larger than 4096 columns")
+    G, c = np.zeros((m, m)), np.zeros(m)
+    ccall("cdh_gram", X.handle, i64(m), ptr(idx), ptr(G), ptr(c), None)
+    w, V = np.linalg.eigh(G)                      # eigen(Symmetric(G))
+    keep = w > 1e-13 * max(w[-1], 0.0)
+    Vk = V[:, keep]
+    pinvG = (Vk / w[keep]) @ Vk.T
+    coef = np.ascontiguousarray(pinvG @ c)
+    res = np.zeros(m)
+    for _ in range(2):
+        ccall("cdh_initialize", X.handle, i64(X.p), i64(m), ptr(idx), ptr(coef))
+        ccall("cdh_xt_r_cols", X.handle, i64(m), ptr(idx), ptr(res))
+        coef = np.ascontiguousarray(coef + pinvG @ res)
+    ccall("cdh_initialize", X.handle, i64(X.p), i64(m), ptr(idx), ptr(coef))
+    X.synced = False
+    return coef
 
 
 def gradient_cache_mode(X):          # gradient_cache_mode(X)
@@ -227,13 +275,7 @@ def scaledLasso_hip(x, X, y, lam, omega, init, sinit, sigmainit, maxIter, optTol
     f = Loss(CDH_LS, y, X)
     if init == "Screening":
         S = findLargestCorrelations(X, y, sinit)
-        idx = np.ascontiguousarray(np.nonzero(S)[0] + 1, dtype=np.int64)
-        m = len(idx)
-        assert m <= 64
-        G, c = np.zeros((m, m)), np.zeros(m)
-        ccall("cdh_gram", X.handle, i64(m), ptr(idx), ptr(G), ptr(c), None)
-        coef = np.ascontiguousarray(np.linalg.solve(G, c))
-        ccall("cdh_initialize", X.handle, i64(X.p), i64(m), ptr(idx), ptr(coef))
+        screening_ols(X, np.ascontiguousarray(np.nonzero(S)[0] + 1, dtype=np.int64))
         sigma = resid_std(X)
         X.owner = f.r
     elif init == "InitStd":
@@ -291,6 +333,7 @@ def xt_y(X, y):                      # xt_y(X, y)
     ccall("cdh_set_y", X.handle, ptr(yy))
     X.owner = None
     ccall("cdh_initialize", X.handle, i64(X.p), i64(0), None, None)
+    X.synced = False
     out = np.zeros(X.p)
     ccall("cdh_xt_r", X.handle, ptr(out))
     return out
@@ -303,13 +346,7 @@ def findLargestCorrelations(X, y, s):            # _findLargestCorrelations(X::H
 
 def findInitResiduals(X, y, s, storage):         # _findInitResiduals!(X::HipMatrix, y, s, storage)
     S = findLargestCorrelations(X, y, s)
-    idx = np.ascontiguousarray(np.nonzero(S)[0] + 1, dtype=np.int64)
-    m = len(idx)
-    assert m <= 64
-    G, c = np.zeros((m, m)), np.zeros(m)
-    ccall("cdh_gram", X.handle, i64(m), ptr(idx), ptr(G), ptr(c), None)
-    coef = np.ascontiguousarray(np.linalg.solve(G, c))
-    ccall("cdh_initialize", X.handle, i64(X.p), i64(m), ptr(idx), ptr(coef))
+    screening_ols(X, np.ascontiguousarray(np.nonzero(S)[0] + 1, dtype=np.int64))
     ccall("cdh_get_residual", X.handle, ptr(storage))
     return storage
 
@@ -545,4 +582,90 @@ def test_lasso_path_hipmatrix_method_moves_nothing_n_sized_and_restores_the_cach
     ccall("cdh_set_gradient_cache", Xh.handle, i32(0))
     LassoPath_hip(Xh, Y, lams[:2], OPT)
     assert gradient_cache_mode(Xh) == 0
+    Xh.close()
+
+
+def test_user_written_pass_over_descend_coordinate_copies_no_residual():
+    """A caller driving the operator interface directly -- the reference's own `_cdPass!` (coordinate_descent.jl:94-110:
+    `for k in it: h = descendCoordinate!(f, g, x, k)`, then dropzeros!) written against the binding -- must not pay an
+    n-sized copy per visit (80 MB at cfg2) nor an upload of the iterate it was just handed: zero residual copies and
+    zero pushes inside the loop; f.r is current again after one explicit pull_residual!."""
+    rng, X, Y = _problem(17, 3000, 40, 6)
+    Xh = HipMatrix(X)
+    f, x = Loss(CDH_LS, Y, Xh), SparseIterate(40)
+    fo, xo, go = O.CDLeastSquaresLoss(Y, X), O.SparseIterate(40), O.ProxL1(0.06)
+    initialize(f, x)
+    O.initialize_(fo, xo)
+    N_RESIDUAL_COPIES[0] = 0
+    pushes0 = N_ITERATE_PUSHES[0]
+    for _ in range(6):                                   # six full passes, visit by visit
+        maxh = 0.0
+        for k in range(1, 41):
+            maxh = max(maxh, abs(descendCoordinate(f, 0.06, None, x, k)))
+        mo = O.cdPass_(xo, fo, go, range(1, 41))
+        np.testing.assert_allclose(maxh, mo, rtol=1e-9, atol=1e-15)
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=1e-12)
+    assert N_RESIDUAL_COPIES[0] == 0 and N_ITERATE_PUSHES[0] == pushes0
+    pull_residual(f)
+    np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-10)
+    Xh.close()
+
+
+def test_lasso_path_hipmatrix_method_keeps_the_carried_residual():
+    """solve_resident! does not push an iterate the handle already holds (it just pulled it): after the first lambda no
+    cdh_set_iterate is issued, so r stays consistent and `cdh_set_reuse_residual` really skips the rebuilds."""
+    rng, X, Y = _problem(18, 3000, 120, 10)
+    Xh = HipMatrix(X)
+    pushes0 = N_ITERATE_PUSHES[0]
+    lams = [0.3, 0.2, 0.1, 0.05]
+    _, path = LassoPath_hip(Xh, Y, lams, OPT, standardizeX=False)
+    assert N_ITERATE_PUSHES[0] - pushes0 <= 1          # the empty x of the first lambda at most
+    lo, bo = O.LassoPath(X, Y, lams, O.CDOptions(**OPT), standardizeX=False)
+    for got, want in zip(path, bo):
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
+    Xh.close()
+
+
+def test_screening_init_with_100_columns_and_with_collinear_ones():
+    """`_findInitResiduals!` takes any s and solves Xs \\ y by QR (utils.jl:65-77).  (1) sinit = 100: the Gram block comes
+    in pairs of 32-column groups.  (2) Two screening columns correlated to 1 - 1e-8: the normal equations alone would
+    square a condition number of ~1e8; eigen-cutoff + refinement gives sigma_init as numpy.linalg.lstsq does."""
+    rng, X, Y = _problem(19, 4000, 300, 120, noise=2.0)
+    Xh = HipMatrix(X)
+    storage = np.zeros(4000)
+    got = findInitResiduals(Xh, Y, 100, storage).copy()
+    c = np.abs(X.T @ Y)
+    S = c >= np.sort(c)[::-1][99]
+    coef, *_ = np.linalg.lstsq(X[:, S], Y, rcond=None)
+    np.testing.assert_allclose(got, Y - X[:, S] @ coef, rtol=0, atol=1e-9)
+    Xh.close()
+    # collinear pair inside the screening set
+    X2 = X.copy()
+    X2[:, 1] = X2[:, 0] + np.sqrt(2e-8) * rng.standard_normal(4000) * np.linalg.norm(X2[:, 0]) / np.sqrt(4000)   # 1 - corr ~ 1e-8
+    Y2 = X2[:, :8] @ (3.0 + rng.standard_normal(8)) + rng.standard_normal(4000)
+    corr = X2[:, 0] @ X2[:, 1] / np.linalg.norm(X2[:, 0]) / np.linalg.norm(X2[:, 1])
+    assert 0.3e-8 < 1 - corr < 3e-8
+    Xh = HipMatrix(np.asfortranarray(X2))
+    c = np.abs(X2.T @ Y2)
+    S = c >= np.sort(c)[::-1][9]
+    assert S[0] and S[1]
+    res = findInitResiduals(Xh, Y2, 10, np.zeros(4000)).copy()
+    coef, *_ = np.linalg.lstsq(X2[:, S], Y2, rcond=None)
+    want = Y2 - X2[:, S] @ coef
+    np.testing.assert_allclose(np.std(res, ddof=1), np.std(want, ddof=1), rtol=1e-8)
+    np.testing.assert_allclose(res, want, rtol=0, atol=1e-6 * np.std(want))
+    Xh.close()
+
+
+def test_resid_std_is_two_pass():
+    """std(f.r) with a mean large against the spread: the one-pass (ss - s^2/n)/(n-1) form loses every digit; cdh_resid_std
+    centres on the device first, as Statistics.std does."""
+    rng = np.random.default_rng(20)
+    n = 20000
+    X = np.asfortranarray(rng.standard_normal((n, 4)))
+    Y = 1e8 + 1e-3 * rng.standard_normal(n)
+    Xh = HipMatrix(X)
+    f, x = Loss(CDH_LS, Y, Xh), SparseIterate(4)
+    initialize(f, x)                                     # r = y
+    np.testing.assert_allclose(resid_std(Xh), np.std(Y, ddof=1), rtol=1e-6)
     Xh.close()

@@ -148,3 +148,25 @@ def test_device_loop_undone_passes_leave_no_trace(monkeypatch):
         assert f.cache_stats()["rollbacks"] > 0 and f.device_loop_stats()["passes"] > 0
         np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-9)
         f.close()
+
+
+@pytest.mark.parametrize("loop", [True, False], ids=["device_loop", "host_loop"])
+def test_sqrt_lasso_near_noiseless_keeps_its_residual_norm(loop):
+    """||r|| << ||y||: the covariance-form visits carry r'r by a recurrence that is only good to ~1e-16 of the value it
+    started from; once it has fallen to 1e-4 of the last value summed from r itself it is summed afresh (gc_q_guard, and
+    kCsNeedQ inside the device loop).  A warm-started sqrt-lasso path on near-noiseless data against the oracle."""
+    rng, X, Y = _problem(91, 3000, 300, 8, noise=1e-5)
+    lams = [6.0, 4.0, 3.0, 2.5, 2.0]
+    o = dict(maxIter=20000, optTol=1e-12, randomize=False)
+    f, fo = cd.CDSqrtLassoLoss(Y, X), O.CDSqrtLassoLoss(Y, X)
+    f.set_gradient_cache(3)
+    f.set_onchip_solve(False)
+    f.set_device_loop(loop)
+    x, xo = cd.SparseIterate(300), O.SparseIterate(300)
+    for lam in lams:
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+        O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert sorted(x.nzval2ind.tolist()) == sorted(xo.nzval2ind.tolist())
+    assert f.cache_stats()["covariance_visits"] > 0
+    f.close()
