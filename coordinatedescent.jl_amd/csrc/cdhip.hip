@@ -1973,9 +1973,11 @@ int32_t cdh_cache_gram_column(cdh_handle h, int64_t k1, double* out_p, double* o
     NEED_H(h);
     NEED_P(h, out_p);
     if (k1 < 1 || k1 > h->p) return fail(h, CDH_BAD_ARG, "coordinate out of range");
-    const GradCache& c = h->gc;
+    GradCache& c = h->gc;
     if (c.slot.empty() || c.slot[(size_t)(k1 - 1)] < 0 || (size_t)c.slot[(size_t)(k1 - 1)] >= c.G.size())
         return fail(h, CDH_BAD_ARG, "the gradient cache holds no Gram column for this coordinate");
+    HIPCHK(h, hipSetDevice(h->device));
+    CHK(gc_host_column(h, c.slot[(size_t)(k1 - 1)]));
     const std::vector<double>& col = c.G[(size_t)c.slot[(size_t)(k1 - 1)]];
     std::memcpy(out_p, col.data(), sizeof(double) * (size_t)h->p);
     if (out_eps) *out_eps = h->dtype == CDH_F32 ? 5.9604644775390625e-8 * kCrossF32EpsFactor / std::sqrt((double)h->n_total) : 0.0;

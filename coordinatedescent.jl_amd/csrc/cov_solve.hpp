@@ -162,10 +162,25 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     for (int s = tid; s < nnz; s += kCsThreads) { const int k = b.in_sup[s]; b.s2i[s] = k; b.i2s[k] = s + 1; }
     __syncthreads();
 
-    int nmoved = 0, status = kCsMaxIter, n_list = 0, dom_any = 0;
+    int nmoved = ctl->n_moved, status = kCsMaxIter, n_list = 0, dom_any = 0;
+    double TV0 = 0.0, lastH = 0.0;
+    {   // the moves still pending on g when the host launched: d_g is the gradient as of the last fold, beta - bfold the moves since
+        double tv_mine = 0.0;
+        for (int m = tid; m < nmoved; m += kCsThreads) {
+            const int km = b.out_moved_idx[m];
+            const double d = b.out_moved_val[m];
+            b.moved[m] = km; b.inmoved[km] = 1; b.bfold[km] = b.beta[km] - d;
+            tv_mine += fabs(d);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tv_mine += __shfl_xor(tv_mine, off, 64);
+        __shared__ double s_tvw[kCsWaves];
+        if ((tid & 63) == 0) s_tvw[tid >> 6] = tv_mine;
+        __syncthreads();
+        for (int wv = 0; wv < kCsWaves; ++wv) TV0 += s_tvw[wv];
+    }
     int pass_id = 1;             // gx_k is current iff gxp[k] == pass_id - 1: k was tracked in the pass just before
     int cnt_prev = -1;           // the tracked list G_UU in LDS was filled for (b.uprev[0 .. cnt_prev))
-    double TV0 = 0.0, lastH = 0.0;
     int64_t passes = 0, full_passes = 0, visits = 0, cov_visits = 0, cov_visits_full = 0, settled_total = 0, folds = 0, exact_rechecks = 0;
 
     auto stage_pending = [&]() {       // pend_m and the column offset of every coordinate moved since the fold
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             int nz_mine = 0, ns_mine = 0, nx_mine = 0;
             const double thr_base = lambda0 * (sqrt_loss ? sqrt(q) : n_total);
             for (int i0 = 0; i0 < L; i0 += kCsThreads * E) {
-                int k[E], sl[E], isl[E];
+                int k[E], sl[E], isl[E], inm[E];
                 bool valid[E], uns[E], nc[E], st[E];
                 double gk[E], bk[E], ak[E], om[E], mk[E];
 #pragma unroll
@@ -260,12 +275,14 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 }
 #pragma unroll
                 for (int e = 0; e < E; ++e) {                        // every load unconditional (clamped index): all in flight together
-                    gk[e] = b.g[k[e]]; bk[e] = b.beta[k[e]]; sl[e] = b.slot[k[e]]; isl[e] = b.i2s[k[e]];
+                    gk[e] = b.g[k[e]]; bk[e] = b.beta[k[e]]; sl[e] = b.slot[k[e]]; isl[e] = b.i2s[k[e]]; inm[e] = b.inmoved[k[e]];
                     ak[e] = b.a[k[e]]; mk[e] = b.colmax[k[e]]; om[e] = has_omega ? b.omega[k[e]] : 1.0;
                 }
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    st[e] = valid[e] & full & (bk[e] == 0.0) & (ak[e] > 0.0) &
+                    // (a coordinate that has itself moved since the fold -- it left the support -- is never settled by the bound:
+                    // M_k leaves out G_kk = a_k, by far the largest entry of its column)
+                    st[e] = valid[e] & full & (bk[e] == 0.0) & (ak[e] > 0.0) & (inm[e] == 0) &
                             (fabs(gk[e]) + mk[e] * TV0 <= thr_base * om[e] * (1.0 - 1e-9) - cert_abs * sqrt(ak[e]));
                     uns[e] = valid[e] & !st[e];
                     nc[e] = uns[e] & (sl[e] < 0);
@@ -740,23 +757,23 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
         // (the gate of run_pass: full passes over dense iterates are not screened at all)
         if (!h->screening || h->x.nnz() * 4 > h->p) return CDH_OK;
         bool go = false;
-        CHK(gc_prepare_full(h, &go, &cert_abs));
+        CHK(gc_prepare_full(h, &go, &cert_abs, false));             // the moves still pending on g go into the kernel with it
         c.prep_state = go ? 1 : 2; c.prep_cert_abs = cert_abs;      // gc_full_pass, if it comes to that, does not prepare twice
-        if (!go) return CDH_OK;
+        if (!go) { gc_fold(h); return CDH_OK; }
     } else {
         if (!c.valid || !c.d_G) return CDH_OK;
         if (gc_support_outgrown(h)) { gc_invalidate(h, false); return CDH_OK; }
         if (c.cov_since_ref > c.refresh_after) CHK(gc_rereference(h));
         for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return CDH_OK;
-        gc_fold(h);
-        if (!c.valid) return CDH_OK;
         gc_q_guard(h);
         if (h->loss == CDH_SQRT) CHK(gc_ensure_q(h));
         CHK(gc_cert_abs(h, &cert_abs));
     }
-    if (!c.d_G || !c.d_scan || !c.moved.empty() || c.dev_slots != (int64_t)c.G.size()) return CDH_OK;
-    for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) if (c.slot[(size_t)h->x.coord(s_)] < 0) return CDH_OK;
-    if (h->x.nnz() > gc_max_support(h)) return CDH_OK;
+    // (from here on a "not now" hands the pass to the round-3 code, which expects the pending moves folded into g)
+    auto not_now = [&]() -> int32_t { gc_fold(h); return CDH_OK; };
+    if (!c.d_G || !c.d_scan || c.dev_slots != (int64_t)c.G.size() || (int64_t)c.moved.size() > h->p) return not_now();
+    for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) if (c.slot[(size_t)h->x.coord(s_)] < 0) return not_now();
+    if (h->x.nnz() > gc_max_support(h)) return not_now();
     // One workgroup serves supports whose Gram block fits its LDS: beyond that every visit's update of the tracked gradients
     // is a gather through one CU (measured at benchmark/cd_bench.jl's shape, 774 non-zeros: 0.38 s against 0.11 s for the
     // pass-by-pass kernels, which spread that update over the chip) -- larger supports stay with those.
@@ -767,9 +784,9 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
         while (ucap > 8 && 8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > budget) ucap -= 4;
     }
     const int64_t support_cap = ucap - kCsTrackedMargin;
-    if (h->x.nnz() > support_cap) return CDH_OK;
+    if (h->x.nnz() > support_cap) return not_now();
     CHK(cs_alloc(h));
-    if (!c.cs_enabled) return CDH_OK;
+    if (!c.cs_enabled) return not_now();
     if (!c.slot_dev_ok) {             // the columns were dropped since the map last went down (a new X): the kernel asks d_slot who has one
         HIPCHK(h, hipMemcpyAsync(c.d_slot, c.slot.data(), sizeof(int32_t) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -792,15 +809,17 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     ctl.busy_limit = kGcBusy; ctl.inject_every = c.inject_rollback; ctl.pad0 = ctl.pad1 = 0;
     ctl.rng = sched.state(); ctl.q = c.q; ctl.q_floor = h->loss == CDH_SQRT ? kGcQGuard * c.q_exact : 0.0;
     ctl.nnz = (int32_t)h->x.nnz(); ctl.prev_conv = *prev_conv ? 1 : 0; ctl.conv = *conv ? 1 : 0; ctl.inject_count = c.inject_count;
-    ctl.status = -1; ctl.n_list = 0; ctl.n_moved = 0;
+    ctl.status = -1; ctl.n_list = 0;
+    ctl.n_moved = (int32_t)c.moved.size();      // in: the moves still pending on g (out: those pending when the kernel stops)
+    for (size_t m = 0; m < c.moved.size(); ++m) { c.cs_out_moved_idx[m] = (int32_t)c.moved[m]; c.cs_out_moved_val[m] = c.dbeta[(size_t)c.moved[m]]; }
     for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) c.cs_in_sup[s_] = (int32_t)h->x.coord(s_);
     CovSolveBufs b = c.cs_bufs;
     b.g = c.d_g; b.Gcols = c.d_G; b.slot = c.d_slot; b.a = c.d_a; b.omega = h->omega; b.beta = h->beta;
     // the tracked coordinates' Gram block (8 u^2 bytes) and arrays (kCsTrackedBytes u, rounded up) next to the shuffle's
     ucap = kCsUcapMax;
     while (ucap > 8 && 8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > c.cs_lds_budget) ucap -= 4;
-    if (h->x.nnz() > ucap - kCsTrackedMargin) return CDH_OK;     // (the budget the runtime really granted is smaller)
-    if (o->randomize && 24 * ((size_t)h->p + 1) > 8 * (size_t)ucap * ucap) return CDH_OK;   // the shuffle's scratch must fit under the Gram block
+    if (h->x.nnz() > ucap - kCsTrackedMargin) return not_now();     // (the budget the runtime really granted is smaller)
+    if (o->randomize && 24 * ((size_t)h->p + 1) > 8 * (size_t)ucap * ucap) return not_now();   // the shuffle's scratch must fit under the Gram block
     const unsigned lds = (unsigned)(8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes);
     hipLaunchKernelGGL(k_cov_solve, dim3(1), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
     HIPCHK(h, hipGetLastError());
@@ -830,11 +849,13 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     }
     for (int64_t k : old_idx) { if (c.cs_old[(size_t)k] != 0.0) note_move(k, -c.cs_old[(size_t)k]); c.cs_old[(size_t)k] = 0.0; }
     // ---- the cache: moves still pending on g, r'r, the counters ----
+    for (int64_t j : c.moved) { c.dbeta[(size_t)j] = 0.0; c.in_moved[(size_t)j] = 0; }      // what went in is in the kernel's list (or folded)
+    c.moved.clear();
     for (int32_t m = 0; m < ctl.n_moved; ++m) {
         const int64_t k = c.cs_out_moved_idx[m];
         const double v = c.cs_out_moved_val[m];
         if (v == 0.0) continue;
-        c.dbeta[(size_t)k] += v;
+        c.dbeta[(size_t)k] = v;
         if (!c.in_moved[(size_t)k]) { c.in_moved[(size_t)k] = 1; c.moved.push_back(k); }
     }
     if (ctl.folds > 0) c.g_host_ok = false;

@@ -73,10 +73,12 @@ int32_t gc_size(cdh_handle h) {   // first use on this handle
 // ---- device mirrors for the covariance-form visits ------------------------------------------------------
 // The Gram columns the host holds are mirrored slot-major on the device (p doubles each), with the slot map;
 // g is sent down before a chunk and comes back after it, so the host copy stays the one truth.
-int32_t gc_dev_upload(cdh_handle h) {
+// room on the device for `have` Gram columns and for what the device-side passes need (first use: the buffers; later: the
+// store grows 64 columns at a time).  c.cov turns false if it cannot be had (on any rank).
+int32_t gc_dev_reserve(cdh_handle h, int64_t have) {
     GradCache& c = h->gc;
     if (!c.cov) return CDH_OK;
-    const int64_t p = h->p, have = (int64_t)c.G.size();
+    const int64_t p = h->p;
     // no room on the device for the mirrors (on any rank) is not an error: the visits stay in residual form
     if (!c.d_g) {
         bool fits = hipMalloc((void**)&c.d_g, sizeof(double) * (size_t)p) == hipSuccess &&
@@ -119,12 +121,33 @@ int32_t gc_dev_upload(cdh_handle h) {
         if (c.d_G) (void)hipFree(c.d_G);
         c.d_G = bigger; c.dev_slots_cap = cap;
     }
-    for (int64_t s_ = c.dev_slots; s_ < have; ++s_)
+    return CDH_OK;
+}
+int32_t gc_dev_upload(cdh_handle h) {
+    GradCache& c = h->gc;
+    if (!c.cov) return CDH_OK;
+    const int64_t p = h->p, have = (int64_t)c.G.size();
+    CHK(gc_dev_reserve(h, have));
+    if (!c.cov) return CDH_OK;
+    for (int64_t s_ = c.dev_slots; s_ < have; ++s_)       // (columns unpacked on the device are there already: gc_fetch)
         HIPCHK(h, hipMemcpyAsync(c.d_G + s_ * p, c.G[(size_t)s_].data(), sizeof(double) * (size_t)p, hipMemcpyHostToDevice, h->stream));
     c.dev_slots = have;
     HIPCHK(h, hipMemcpyAsync(c.d_slot, c.slot.data(), sizeof(int32_t) * (size_t)p, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     c.slot_dev_ok = true;
+    return CDH_OK;
+}
+
+// The host's copy of Gram column `s`: columns that went straight into the device store (gc_fetch) come over when host
+// code first asks for them -- the careful walk's re-check, a fold without device mirrors, cdh_cache_gram_column.
+int32_t gc_host_column(cdh_handle h, int64_t s_) {
+    GradCache& c = h->gc;
+    std::vector<double>& col = c.G[(size_t)s_];
+    if (!col.empty()) return CDH_OK;
+    if (!c.d_G || s_ >= c.dev_slots) return fail(h, CDH_BAD_ARG, "gradient cache: a Gram column is neither on the host nor on the device");
+    col.resize((size_t)h->p);
+    HIPCHK(h, hipMemcpyAsync(col.data(), c.d_G + s_ * h->p, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return CDH_OK;
 }
 
@@ -480,25 +503,36 @@ int32_t gc_fetch(cdh_handle h, const std::vector<int64_t>& cols) {
                            c.cross_J, c.d_cross);
         HIPCHK(h, hipGetLastError());
         CHK(allreduce(h, c.d_cross, (size_t)launches * kCrossRec));
-        HIPCHK(h, hipMemcpyAsync(c.h_cross.data(), c.d_cross, sizeof(double) * (size_t)launches * kCrossRec,
-                                 hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));   // also: todo[b0 ..] has been consumed
-        for (int b = 0; b < nbc; ++b) {
-            c.G.emplace_back((size_t)h->p, 0.0);
-            std::vector<double>& col = c.G.back();
-            for (int64_t k = 0; k < h->p; ++k) {
-                const int64_t L = k / kCrossA, i = k % kCrossA;
-                col[(size_t)k] = c.h_cross[(size_t)(L * kCrossRec + ((i >> 4) * kCrossTB + (b >> 4)) * 256 + (i & 15) * 16 + (b & 15))];
-            }
-            c.slot[(size_t)todo[b0 + (size_t)b]] = (int32_t)(c.G.size() - 1);
-        }
         c.n_batches += 1; c.n_columns += nbc;
-        // the batch's columns go into the device store straight from the cross-product records where it has room (no trip
-        // through the host for them: 32 pageable uploads of p doubles each were ~1 ms per batch at p = 5000)
-        if (c.cov && c.d_G && c.dev_slots + nbc == (int64_t)c.G.size() && (int64_t)c.G.size() <= c.dev_slots_cap) {
+        // Where the device store has room, the batch's columns go into it straight from the cross-product records (round 4):
+        // no copy of the records to the host, no host-side unpacking, no 32 pageable uploads -- ~1.5 ms per batch at p = 5000 --
+        // and the host does not wait for k_cross at all.  The host's copies are fetched when host code asks (gc_host_column).
+        bool on_device = false;
+        if (c.cov && c.dev_slots == (int64_t)c.G.size()) {
+            CHK(gc_dev_reserve(h, (int64_t)c.G.size() + nbc));
+            on_device = c.cov && c.d_G && (int64_t)c.G.size() + nbc <= c.dev_slots_cap;
+        }
+        if (on_device) {
             hipLaunchKernelGGL(k_cross_unpack, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_cross, h->p, (int)c.dev_slots, nbc, c.d_G);
             HIPCHK(h, hipGetLastError());
+            for (int b = 0; b < nbc; ++b) {
+                c.G.emplace_back();
+                c.slot[(size_t)todo[b0 + (size_t)b]] = (int32_t)(c.G.size() - 1);
+            }
             c.dev_slots += nbc;
+        } else {
+            HIPCHK(h, hipMemcpyAsync(c.h_cross.data(), c.d_cross, sizeof(double) * (size_t)launches * kCrossRec,
+                                     hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            for (int b = 0; b < nbc; ++b) {
+                c.G.emplace_back((size_t)h->p, 0.0);
+                std::vector<double>& col = c.G.back();
+                for (int64_t k = 0; k < h->p; ++k) {
+                    const int64_t L = k / kCrossA, i = k % kCrossA;
+                    col[(size_t)k] = c.h_cross[(size_t)(L * kCrossRec + ((i >> 4) * kCrossTB + (b >> 4)) * 256 + (i & 15) * 16 + (b & 15))];
+                }
+                c.slot[(size_t)todo[b0 + (size_t)b]] = (int32_t)(c.G.size() - 1);
+            }
         }
         CHK(gc_dev_upload(h));
     }
@@ -545,6 +579,7 @@ void gc_fold(cdh_handle h) {
     for (int64_t j : c.moved) {
         const double d = c.dbeta[(size_t)j];
         if (!on_device && d != 0.0) {
+            (void)gc_host_column(h, c.slot[(size_t)j]);
             const std::vector<double>& col = c.G[(size_t)c.slot[(size_t)j]];
             for (int64_t k = 0; k < h->p; ++k) c.g[(size_t)k] -= d * col[(size_t)k];
         }
@@ -681,7 +716,7 @@ struct GcThresholds {             // the certificates' bounds as the host evalua
     double cert(int64_t k) const { return thr_of(k) - cert_abs * std::sqrt(h->gc.a[(size_t)k]); }
     double ratio(int64_t k) const { return std::fabs(h->gc.g[(size_t)k]) / thr_of(k); }
 };
-int32_t gc_prepare_full(cdh_handle h, bool* go, double* cert_abs_out) {
+int32_t gc_prepare_full(cdh_handle h, bool* go, double* cert_abs_out, bool fold = true /* false: the caller carries the pending moves itself (cov_solve) */) {
     GradCache& c = h->gc;
     *go = false;
     c.full_seen += 1;
@@ -736,7 +771,7 @@ int32_t gc_prepare_full(cdh_handle h, bool* go, double* cert_abs_out) {
         if (c.mode == 0) return CDH_OK;
     }
     for (int64_t j : c.moved) if (c.slot[(size_t)j] < 0) return fail(h, CDH_BAD_ARG, "gradient cache: a moved coordinate has no Gram column");
-    gc_fold(h);
+    if (fold) gc_fold(h);
     if (!c.valid) return CDH_OK;      // (a device fold that failed hard leaves no gradient: the pass runs the plain way)
     gc_q_guard(h);
     if (h->loss == CDH_SQRT) CHK(gc_ensure_q(h));
@@ -862,6 +897,7 @@ int32_t gc_full_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH,
                                     if (q_run < 0.0) q_run = 0.0;
                                     rnorm = std::sqrt(q_run);
                                 }
+                                CHK(gc_host_column(h, c.slot[(size_t)kv]));
                                 const std::vector<double>& col = c.G[(size_t)c.slot[(size_t)kv]];
                                 for (int64_t kk = 0; kk < h->p; ++kk) gv[(size_t)kk] -= hv * col[(size_t)kk];
                             }
