@@ -67,7 +67,9 @@ def _switch_paths(rng, f, log):
         f.set_use_graph(on)
         log.append(f"graph {on}")
     else:
-        log.append("no switch")
+        on = bool(rng.integers(0, 3))                  # (off one time in three: the pass loop of cache-served solves on the host)
+        f.set_device_loop(on)
+        log.append(f"device loop {on}")
 
 
 def _check_iterates(x, xo, log, strict_order=True):

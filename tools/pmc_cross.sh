@@ -13,7 +13,7 @@ done
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
-def short(n): return n.split("(")[0].replace("void ", "").replace("cdk::", "")[:72]
+def short(n): return n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("cdk::", "")[:72]
 for C in ("FETCH_SIZE", "WRITE_SIZE", "MfmaUtil"):
     g = glob.glob(f"{out}/pmc_{C}/**/*counter_collection.csv", recursive=True)
     if not g:

@@ -19,7 +19,7 @@ $R/exp/cross_bench 2000000 5000 2 f32 > $OUT/cross_bench_f32.txt 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
-def short(n): return n.split("(")[0].replace("void ", "").replace("cdk::", "")[:64]
+def short(n): return n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("cdk::", "")[:64]
 f = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
 print("# kernel trace of tools/bench_configs.py cfg3 (n = 2e6, p = 5000, 100 lambdas)")
 if f:

@@ -37,5 +37,5 @@ for mode in (1, 3, 0):
 if os.environ.get("CPU"):
     import oracle as O  # noqa: E402
     t0 = time.perf_counter()
-    po = O.LassoPath(X, Y, lams, O.CDOptions(**o))
-    print("CPU port, one core: %.3f s" % (time.perf_counter() - t0), "max |dbeta| %.2e" % float(np.max(np.abs(po.betapath[-1].dense() - ref))))
+    lo, bo = O.LassoPath(X, Y, lams, O.CDOptions(**o))
+    print("CPU port, one core: %.3f s" % (time.perf_counter() - t0), "max |dbeta| %.2e" % float(np.max(np.abs(bo[-1] - ref))))

@@ -18,7 +18,7 @@ def find(pattern):
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     return name.replace("void ", "").replace("cdk::", "")[:60]
 
 
