@@ -116,6 +116,15 @@ def main():
     except cd.HipError as e:
         assert "exchange" in str(e)
     cp.barrier()
+    # ... and an exchange installed AFTER the loss puts the shard back to work (only the host-exchange install
+    # used to clear the refusal; here the direct exchange replaces the transport that was taken away)
+    assert sharded.connect_p2p(f, cp, selftest=True), "p2p self-test failed"
+    x, xo = cd.SparseIterate(p), O.SparseIterate(p)
+    cd.coordinateDescent_(x, f, cd.ProxL1(0.08, om), cd.CDOptions(**o))
+    O.coordinateDescent_(xo, O.CDLeastSquaresLoss(y, X), O.ProxL1(0.08, om), O.CDOptions(**o))
+    assert float(np.max(np.abs(x.dense() - xo.dense()))) < 1e-10 and same_on_all_ranks(x.dense())
+    assert f.exchange_stats()["p2p_calls"] > 0
+    cp.barrier()
     f.close()
     # Near-equal shards on opposite sides of the default-width cut (cdh_create: B = 64 below 262 144 local rows, else 32):
     # 524 287 rows over two ranks are 262 144 + 262 143.  Nobody sets a width here -- the handles agree on one through the
