@@ -33,10 +33,13 @@
 constexpr int kCsThreads = 256;          // 4 waves, one per SIMD: gram_scalar_body<4> holds a 64-entry Gram column per lane (128 VGPRs) next to the loops' state
 constexpr int kCsWaves = kCsThreads / 64;
 constexpr int kCsNearMax = 96;           // inactive coordinates failing the bound beyond which the kernel folds and scans again
-constexpr int64_t kCsShuffleMaxP = 5120;    // the shuffle's six (p + 1)-sized int arrays must fit LDS (under the smallest tracked Gram block)
+constexpr int64_t kCsShuffleMaxP = 5600;    // the shuffle's six (p + 1)-sized int arrays must fit LDS (under the smallest tracked Gram block)
 constexpr size_t kCsLdsBudget = (size_t)134 * 1024;   // dynamic LDS next to ~24 KB of static arrays (160 KB per CU)
 constexpr int kCsTrackedMargin = 24;     // room in the tracked list for entering and near-threshold coordinates next to the support
-constexpr int kCsUcapMax = 124;          // tracked coordinates whose Gram block is kept in LDS (124 x 124 doubles = 120 KB)
+constexpr int kCsUcapMax = 176;          // tracked coordinates whose Gram block is kept in LDS: symmetric, upper triangle packed (176 x 177 / 2 doubles = 122 KB)
+__host__ __device__ constexpr size_t cs_tri_doubles(size_t u) { return u * (u + 1) / 2; }
+// index of G_UU[i][j], i <= j, in the packed upper triangle of a cnt x cnt block (row i starts after rows 0 .. i - 1)
+__device__ __forceinline__ int cs_tri(int i, int j, int cnt) { return i * cnt - (i * (i - 1)) / 2 + (j - i); }
 
 // Ranks inside a block, E positions per thread (thread t owns positions base + E t .. base + E t + E - 1: rank order is
 // position order).  rank[e] = exclusive rank of flag[e]; returns the block's total.  s_w: 2 * kCsWaves ints of LDS.
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     using R = GramRec<4>;
     constexpr int B = R::B;
     constexpr int E = kCsE;
-    extern __shared__ double s_dynamic[];        // [G_UU: ucap x ucap doubles; a shuffle's scratch overlays it][tracked arrays: 84 ucap bytes]
+    extern __shared__ double s_dynamic[];        // [G_UU: upper triangle of ucap x ucap doubles, packed; a shuffle's scratch overlays it][tracked arrays: 84 ucap bytes]
     __shared__ double s_rec[R::N];
     __shared__ int s_mu[B];
     __shared__ double s_h[B];
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     double* s_G = s_dynamic;
     CsTracked lt;                                 // the LDS copy of the tracked arrays
     {
-        double* d = s_dynamic + (size_t)ucap * ucap;
+        double* d = s_dynamic + cs_tri_doubles((size_t)ucap);
         lt.k = reinterpret_cast<int64_t*>(d); d += ucap;
         lt.voff = reinterpret_cast<int64_t*>(d); d += ucap;
         lt.iota = reinterpret_cast<int64_t*>(d); d += ucap;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         const bool direct = full && !randomize;      // an ordered full pass visits k = i: no list
         // ---- reset!(it, full) + collect(it) (atom_iterator.jl:34-37, 53-64; the splitmix64 substitute of sparse_iterate.hpp) ----
         if (randomize) {
-            // the shuffle's six (p + 1)-sized arrays overlay the tracked Gram block in LDS, which is refilled below anyway (a
+            // the shuffle's six (p + 1)-sized arrays overlay the tracked Gram block (and arrays) in LDS, which are refilled below anyway (a
             // shuffled pass visits its coordinates in a new order); Fisher-Yates itself without the serial swaps: small_solve.hpp
             int32_t* f_draw = reinterpret_cast<int32_t*>(s_dynamic);
             int32_t *f_cnt = f_draw + (p + 1), *f_off = f_cnt + (p + 1), *f_bucket = f_off + (p + 1), *f_par = f_bucket + (p + 1), *f_out = f_par + (p + 1);
@@ -239,7 +242,9 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             __syncthreads();
             parallel_fisher_yates<kCsThreads>(tid, L, f_draw, f_cnt, f_off, f_bucket, f_par, f_out, s_w, [] { __syncthreads(); });
             for (int i = tid; i < L; i += kCsThreads) b.list[i] = full ? f_out[i] : b.s2i[f_out[i]];
-            cnt_prev = -1;
+            __syncthreads();
+            for (int u = tid; u < ucap; u += kCsThreads) lt.iota[u] = u;      // (the scratch may reach into the tracked arrays: all of
+            cnt_prev = -1;                                                    // them are rebuilt per pass but this one)
         } else if (!full) {
             for (int i = tid; i < L; i += kCsThreads) b.list[i] = b.s2i[i];
         }
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         const double q_start = q;
         __syncthreads();
         if (in_lds && !s_same) {         // G_UU[i][j] = X_ki' X_kj for the tracked coordinates (symmetric; row i contiguous)
-            for (int e = tid; e < cnt * cnt; e += kCsThreads) { const int i = e / cnt, j = e - i * cnt; s_G[e] = b.Gcols[T.voff[j] + T.k[i]]; }
+            for (int e = tid; e < cnt * cnt; e += kCsThreads) { const int i = e / cnt, j = e - i * cnt; if (i <= j) s_G[cs_tri(i, j, cnt)] = b.Gcols[T.voff[j] + T.k[i]]; }
             for (int u = tid; u < cnt; u += kCsThreads) b.uprev[u] = T.k[u];
             cnt_prev = cnt;
         } else if (!in_lds) {
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             const int nb = min(B, cnt - j0);
             for (int e = tid; e < B * B; e += kCsThreads) {
                 const int sI = e / B, j = e % B;
-                if (sI <= j && j < nb) s_rec[R::g(sI, j)] = in_lds ? s_G[(j0 + sI) * cnt + j0 + j] : b.Gcols[T.voff[j0 + j] + T.k[j0 + sI]];
+                if (sI <= j && j < nb) s_rec[R::g(sI, j)] = in_lds ? s_G[cs_tri(j0 + sI, j0 + j, cnt)] : b.Gcols[T.voff[j0 + j] + T.k[j0 + sI]];
             }
             if (tid < B) s_rec[R::OFF_C + tid] = (tid < nb) ? T.gx[j0 + tid] : 0.0;
             if (tid == 0) s_rec[R::OFF_Q] = s_ctrl.q_carry;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             if (nmove > 0)               // every tracked coordinate sees the block's moves (the block's own members too: gx stays current)
                 for (int u = tid; u < cnt; u += kCsThreads) {
                     double acc = T.gx[u];
-                    if (in_lds) { for (int i = 0; i < nmove; ++i) acc = fma(-s_h[i], s_G[s_mu[i] * cnt + u], acc); }
+                    if (in_lds) { for (int i = 0; i < nmove; ++i) { const int mv = s_mu[i]; acc = fma(-s_h[i], s_G[cs_tri(min(mv, u), max(mv, u), cnt)], acc); } }
                     else { const int64_t k = T.k[u]; for (int i = 0; i < nmove; ++i) acc = fma(-s_h[i], b.Gcols[T.voff[s_mu[i]] + k], acc); }
                     T.gx[u] = acc;
                 }
@@ -781,7 +786,7 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     int ucap = kCsUcapMax;
     {
         const size_t budget = c.cs_lds_budget ? c.cs_lds_budget : kCsLdsBudget;
-        while (ucap > 8 && 8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > budget) ucap -= 4;
+        while (ucap > 8 && 8 * cs_tri_doubles((size_t)ucap) + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > budget) ucap -= 4;
     }
     const int64_t support_cap = ucap - kCsTrackedMargin;
     if (h->x.nnz() > support_cap) return not_now();
@@ -817,10 +822,10 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     b.g = c.d_g; b.Gcols = c.d_G; b.slot = c.d_slot; b.a = c.d_a; b.omega = h->omega; b.beta = h->beta;
     // the tracked coordinates' Gram block (8 u^2 bytes) and arrays (kCsTrackedBytes u, rounded up) next to the shuffle's
     ucap = kCsUcapMax;
-    while (ucap > 8 && 8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > c.cs_lds_budget) ucap -= 4;
+    while (ucap > 8 && 8 * cs_tri_doubles((size_t)ucap) + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > c.cs_lds_budget) ucap -= 4;
     if (h->x.nnz() > ucap - kCsTrackedMargin) return not_now();     // (the budget the runtime really granted is smaller)
-    if (o->randomize && 24 * ((size_t)h->p + 1) > 8 * (size_t)ucap * ucap) return not_now();   // the shuffle's scratch must fit under the Gram block
-    const unsigned lds = (unsigned)(8 * (size_t)ucap * ucap + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes);
+    const unsigned lds = (unsigned)(8 * cs_tri_doubles((size_t)ucap) + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes);
+    if (o->randomize && 24 * ((size_t)h->p + 1) > (size_t)lds) return not_now();   // the shuffle's scratch overlays the dynamic LDS
     hipLaunchKernelGGL(k_cov_solve, dim3(1), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
