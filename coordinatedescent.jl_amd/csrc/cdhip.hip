@@ -1632,7 +1632,6 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
         rc = small_solve(h, opt, &lam, 1, &rng, &st, true);
     } else if (small) {
         const double target = h->ctrl.lambda0;
-        const cdh::SupportList x_before = h->x;
         h->x.clear();                                   // fill!(x, 0)           (:25)
         HIPCHK(h, hipMemsetAsync(h->beta, 0, sizeof(double) * h->p, h->stream));
         // _findLambdaMax (:29) at r = y: max_k |X_k'y| / n / omega_k (sqrt-lasso: / ||y||) -- from the cached X'y
@@ -1651,7 +1650,6 @@ static int32_t cdh_coordinate_descent_impl(cdh_handle h, const cdh_options* opt,
         std::vector<double> grid((size_t)opt->numSteps + 1);   // the numSteps + 1 solves of (:32-36) inside one launch
         for (int64_t j = 0; j <= opt->numSteps; ++j) grid[(size_t)j] = std::exp((j == opt->numSteps) ? l2 : l1 + (double)j * step);
         rc = small_solve(h, opt, grid.data(), (int)grid.size(), &rng, &st, true);
-        (void)x_before;
     }
     if (small && rc == kSmallPrecisionLost) { small = false; st = cdh_stats{}; rc = CDH_OK; }
     if (small) {

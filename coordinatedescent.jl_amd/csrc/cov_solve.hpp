@@ -16,24 +16,36 @@
 //
 // What a full pass costs.  g lives in d_g for all p coordinates, but only the coordinates a pass really visits (the support
 // and the few inactive ones near their threshold) need it exactly at every step.  So d_g is kept as it stood at the last
-// FOLD and the moves since then stay pending (moved[], beta - bfold): the visited ("tracked") coordinates get their exact
-// gradient at the start of every pass, gx_k = g_k - sum_m pend_m G_mk, and keep it current visit by visit; everybody else is
-// certified against a BOUND:   |g_k(t)| <= |g_k| + M_k TV(t),   M_k = max_j |G_jk| over the cached columns j != k,
+// FOLD and the moves since then stay pending (moved[], beta - bfold; those pending when the host launches travel in with
+// the launch): the visited ("tracked") coordinates carry their exact gradient -- computed once, gx_k = g_k - sum_m pend_m G_mk,
+// then kept current visit by visit and from pass to pass -- together with beta, omega and the packed upper triangle of their
+// Gram block in LDS, so the visits themselves touch no global memory; everybody else is certified against a BOUND:
+//     |g_k(t)| <= |g_k| + M_k TV(t),   M_k = max_j |G_jk| over the cached columns j != k,
 // TV(t) = the total variation sum |h| of all moves since the fold up to time t (it only grows, and it is recorded per visit).
-// A coordinate is skipped as settled when the bound at the start of the pass is under its certificate, and re-checked after
-// the pass with the bound AT ITS TURN (TV and, for the sqrt-lasso, r'r as they stood when its turn came); one whose bound no
-// longer holds gets its exact gradient at its turn (a gather along the moved coordinates' columns), and only if THAT breaks
-// the certificate is the pass undone and handed to the host's careful walk.  On a Gaussian design M_k TV is ~1e-3 of a
-// threshold: a full pass reads p numbers, not p x (moves) Gram entries -- the round-3 device pass moved 4 MB through the CUs
-// per full pass of cfg3 for the g update alone.  When the bound has grown loose (many inactive coordinates fail it) the
-// kernel folds: g -= sum_m pend_m G_m over all p, TV = 0.  Same iterates, support order and pass counts as visiting every
-// coordinate (tests: the legs of tests/_legs.py, the stateful fuzz, tests/test_gpu_cov_solve.py).
+// A coordinate is skipped as settled when the bound at the start of the pass is under its certificate -- never one that has
+// itself moved since the fold: M_k leaves out G_kk -- and re-checked after the pass with the bound AT ITS TURN (TV and, for
+// the sqrt-lasso, r'r as they stood when its turn came); one whose bound no longer holds gets its exact gradient at its turn
+// (a gather along the moved coordinates' columns), and only if THAT breaks the certificate is the pass undone (beta itself
+// is written back only when a pass is accepted) and handed to the host's careful walk.  On a Gaussian design M_k TV is ~1e-3
+// of a threshold: a full pass reads p numbers, not p x (moves) Gram entries -- the round-3 device pass moved 4 MB through the
+// CUs per full pass of cfg3 for the g update alone.  When the bound has grown loose (many inactive coordinates fail it, or
+// one without a Gram column does) the kernel folds: g -= sum_m pend_m G_m over all p, TV = 0.
+// ProximalBase's bookkeeping without its p transient slots: the final slot order of a pass is assembled from the old slots
+// and the visited appenders only (see "analytic" below); the straightforward replay stays for the rare exceptions.
+// What it is NOT for: supports beyond the LDS-sized Gram block (~150 non-zeros).  There every visit's update of the tracked
+// gradients is a gather through ONE CU (0.38 s against 0.11 s for the pass-by-pass kernels at benchmark/cd_bench.jl's shape,
+// 774 non-zeros): the host keeps those.
+// Why it looks the way it does (measured, LAB_NOTES.md round 4): on one CU every dependent global access is 0.2-0.5 us, so
+// the p-sized loops issue all their loads unconditionally (clamped indices, no short-circuit conditions: a conditional load
+// is compiled into a load that is waited for on its own) and rank several flags per pair of barriers.
+// Same iterates, support order and pass counts as visiting every coordinate (tests: the legs of tests/_legs.py, the stateful
+// fuzz, tests/test_gpu_cov_solve.py).
 #pragma once
 
 constexpr int kCsThreads = 256;          // 4 waves, one per SIMD: gram_scalar_body<4> holds a 64-entry Gram column per lane (128 VGPRs) next to the loops' state
 constexpr int kCsWaves = kCsThreads / 64;
 constexpr int kCsNearMax = 96;           // inactive coordinates failing the bound beyond which the kernel folds and scans again
-constexpr int64_t kCsShuffleMaxP = 5600;    // the shuffle's six (p + 1)-sized int arrays must fit LDS (under the smallest tracked Gram block)
+constexpr int64_t kCsShuffleMaxP = 5600;    // the shuffle's six (p + 1)-sized int arrays must fit the kernel's dynamic LDS
 constexpr size_t kCsLdsBudget = (size_t)134 * 1024;   // dynamic LDS next to ~24 KB of static arrays (160 KB per CU)
 constexpr int kCsTrackedMargin = 24;     // room in the tracked list for entering and near-threshold coordinates next to the support
 constexpr int kCsUcapMax = 176;          // tracked coordinates whose Gram block is kept in LDS: symmetric, upper triangle packed (176 x 177 / 2 doubles = 122 KB)
