@@ -430,10 +430,11 @@ class _HipLoss(CoordinateDifferentiableFunction):
             self._push(x, rebuild=False)
 
     def _pull(self, x):
-        idx = np.zeros(max(self.p, 1), dtype=np.int64)
+        if getattr(self, "_pull_idx", None) is None:      # (two p-sized host buffers, kept: a path pulls once per lambda)
+            self._pull_idx, self._pull_beta = np.zeros(max(self.p, 1), dtype=np.int64), np.zeros(self.p)
+        idx, beta = self._pull_idx, self._pull_beta
         nnz = C.c_int64()
         check(self._L.cdh_get_support(self._h, _vp(idx), C.byref(nnz)), self._h)
-        beta = np.zeros(self.p)
         check(self._L.cdh_get_beta(self._h, _vp(beta)), self._h)
         sup = idx[: nnz.value]
         x._load(sup, beta[sup - 1])
