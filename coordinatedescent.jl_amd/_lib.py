@@ -140,6 +140,7 @@ def lib():
         "cdh_get_gradient_cache": [vp, P(i32)],
         "cdh_set_device_loop": [vp, i32],
         "cdh_device_loop_stats": [vp, P(i64)],
+        "cdh_device_loop_table": [vp, P(i64)],
         "cdh_set_onchip_solve": [vp, i32],
         "cdh_onchip_stats": [vp, P(i64)],
         "cdh_onchip_last": [vp, P(i64)],

@@ -340,6 +340,10 @@ class _HipLoss(CoordinateDifferentiableFunction):
         d = dict(zip(("launches", "passes", "folds", "exact_rechecks"), [int(x) for x in out[:4]]))
         d["phase_us"] = dict(zip(("list", "scan", "exact_g", "visits", "recheck", "accept", "bookkeeping", "dropzeros_rest"),
                                  [int(x) / 100.0 for x in out[4:]]))
+        t = (C.c_int64 * 6)()
+        check(self._L.cdh_device_loop_table(self._h, t), self._h)
+        d["table"] = dict(zip(("passes", "rows_filled", "coordinates", "capacity"), [int(x) for x in t[:4]]))
+        d["forced_rounds"] = {"host_pass": int(t[4]), "loop": int(t[5])}
         return d
 
     def set_use_graph(self, on=True):

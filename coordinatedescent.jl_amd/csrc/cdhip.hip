@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 
 #include "kernels.hpp"
 #include "gram_kernels.hpp"
@@ -112,7 +113,9 @@ struct GradCache {
     int64_t* d_pass_idx = nullptr;        // the pass's visit list (0-based), as uploaded last
     std::vector<int64_t> pass_idx_host;   // ... and what it holds
     int32_t *d_pos_of = nullptr, *d_upos = nullptr;
-    uint8_t* d_setflag = nullptr;
+    uint8_t *d_setflag = nullptr, *d_forced = nullptr;   // (d_forced: the second half of d_setflag's allocation)
+    bool forced_dirty = false;
+    int64_t n_forced_rounds = 0, n_cs_forced_rounds = 0;
     // the scan's counters sit at the head of the buffer of unsettled positions (one copy brings both back); the results of
     // a pass come back through k_cov_pack's block
     int32_t *d_scanbuf = nullptr, *h_scanbuf = nullptr;   // [CovScanOut: 4 int32][positions: cap]; h_: pinned
@@ -151,8 +154,10 @@ struct GradCache {
     std::vector<double> cs_old;      // scratch: the iterate's values before a launch, by coordinate (zero between launches)
     int prep_state = 0;              // gc_prepare_full has run for the pass about to be walked: 1 go, 2 no-go (0: not yet)
     double prep_cert_abs = 0.0;
-    int64_t n_cs_launches = 0, n_cs_passes = 0, n_cs_folds = 0, n_cs_exact = 0;
-    int64_t cs_ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs_cycles = 0, cs_ticks_total = 0;
+    int64_t n_cs_launches = 0, n_cs_passes = 0, n_cs_folds = 0, n_cs_exact = 0, n_cs_table_passes = 0, n_cs_table_rows = 0;
+    int32_t cs_ncid = 0, cs_tepoch = 0;      // the kernel's Gram table: coordinates it holds, the epoch of its carried gradients
+    bool cs_table_reset = true;
+    int64_t cs_ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs_cycles = 0, cs_ticks_total = 0, cs_dbg[4] = {0, 0, 0, 0};
 };
 
 // The one-launch solve of problems that fit on chip (small_solve.hpp): the full Gram matrix of the resident X, the
@@ -585,6 +590,7 @@ void gc_invalidate(cdh_handle h, bool columns) {
         std::fill(c.slot.begin(), c.slot.end(), -1);
         c.slot_dev_ok = false;           // d_slot still names the old columns until the next upload (cov_solve.hpp reads it)
         c.colmax_slots = 0;
+        c.cs_table_reset = true;         // ... and so does the device loop's Gram table
         c.dev_slots = 0;                 // the device store is refilled from slot 0 (its memory is kept)
         c.full_seen = 0;
     }
@@ -1077,6 +1083,7 @@ int32_t run_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, boo
 }
 
 // _coordinateDescent! (coordinate_descent.jl:65-92)
+double g_dbg_pass_us[2] = {0, 0}; long g_dbg_pass_n[2] = {0, 0};
 int32_t solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched, cdh_stats* st) {
     bool prev_converged = false, converged = true;
     std::vector<int64_t> visit;
@@ -1093,8 +1100,10 @@ int32_t solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched, cd
         const bool full = converged;
         sched.next_pass(h->x, full, visit);
         double maxH = 0.0;
+        const auto dbg_t0 = std::chrono::steady_clock::now();
         if (!visit.empty()) CHK(run_pass(h, visit.data(), (int64_t)visit.size(), &maxH, full));
         else h->x.dropzeros();
+        { const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count(); g_dbg_pass_us[full ? 0 : 1] += us; g_dbg_pass_n[full ? 0 : 1] += 1; }
         h->gc.prep_state = 0;
         st->passes += 1; st->visits += (int64_t)visit.size(); st->maxH = maxH;
         if (full) st->full_passes += 1;
@@ -1993,7 +2002,18 @@ int32_t cdh_device_loop_stats(cdh_handle h, int64_t* out12) {
     NEED_P(h, out12);
     out12[0] = h->gc.n_cs_launches; out12[1] = h->gc.n_cs_passes; out12[2] = h->gc.n_cs_folds; out12[3] = h->gc.n_cs_exact;
     for (int i = 0; i < 8; ++i) out12[4 + i] = h->gc.cs_ticks[i];
+    if (getenv("CDH_PASS_TIMES")) fprintf(stderr, "visits phase: staging %.0f us, visits %.0f us, after-visit %.0f us, gradient update %.0f us\n", h->gc.cs_dbg[0] / 100.0, h->gc.cs_dbg[1] / 100.0, h->gc.cs_dbg[2] / 100.0, h->gc.cs_dbg[3] / 100.0);
+    if (getenv("CDH_PASS_TIMES")) fprintf(stderr, "host device passes: scan+sync %.0f us, blocks+fetch %.0f us, bookkeeping %.0f us\n", g_dbg_scan_us, g_dbg_blocks_us, g_dbg_book_us);
+    if (getenv("CDH_PASS_TIMES")) fprintf(stderr, "host passes: full %ld in %.0f us, active %ld in %.0f us\n", g_dbg_pass_n[0], g_dbg_pass_us[0], g_dbg_pass_n[1], g_dbg_pass_us[1]);
     if (getenv("CDH_COV_SOLVE_CLOCK")) fprintf(stderr, "k_cov_solve: %lld cycles in %lld ticks of 10 ns: %.3f GHz\n", (long long)h->gc.cs_cycles, (long long)h->gc.cs_ticks_total, h->gc.cs_ticks_total ? (double)h->gc.cs_cycles / (double)h->gc.cs_ticks_total * 0.1 : 0.0);
+    return CDH_OK;
+}
+
+int32_t cdh_device_loop_table(cdh_handle h, int64_t* out6) {
+    NEED_H(h);
+    NEED_P(h, out6);
+    out6[0] = h->gc.n_cs_table_passes; out6[1] = h->gc.n_cs_table_rows; out6[2] = h->gc.cs_table_reset ? 0 : h->gc.cs_ncid; out6[3] = kCsTableCap;
+    out6[4] = h->gc.n_forced_rounds; out6[5] = h->gc.n_cs_forced_rounds;
     return CDH_OK;
 }
 

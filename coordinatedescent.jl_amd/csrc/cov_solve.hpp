@@ -48,6 +48,10 @@ constexpr int kCsNearMax = 96;           // inactive coordinates failing the bou
 constexpr int64_t kCsShuffleMaxP = 5600;    // the shuffle's six (p + 1)-sized int arrays must fit the kernel's dynamic LDS
 constexpr size_t kCsLdsBudget = (size_t)134 * 1024;   // dynamic LDS next to ~24 KB of static arrays (160 KB per CU)
 constexpr int kCsTrackedMargin = 24;     // room in the tracked list for entering and near-threshold coordinates next to the support
+constexpr int kCsTableCap = 1536;        // coordinates the Gram table of large visit lists holds (1536^2 doubles = 18.9 MB of device memory)
+constexpr int kCsTableMargin = 160;      // ... of which this many are left to entering and near-threshold coordinates next to the support
+constexpr size_t kCsTableLds = 2688 + 64 * 64;    // doubles of dynamic LDS table mode uses (a GramRec<4> record rounded up, a tile)
+constexpr int kCsForcedRounds = 4;       // a full pass whose re-check found coordinates crossing their threshold is run again this often with those visited
 constexpr int kCsUcapMax = 176;          // tracked coordinates whose Gram block is kept in LDS: symmetric, upper triangle packed (176 x 177 / 2 doubles = 122 KB)
 __host__ __device__ constexpr size_t cs_tri_doubles(size_t u) { return u * (u + 1) / 2; }
 // index of G_UU[i][j], i <= j, in the packed upper triangle of a cnt x cnt block (row i starts after rows 0 .. i - 1)
@@ -132,10 +136,12 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     extern __shared__ double s_dynamic[];        // [G_UU: upper triangle of ucap x ucap doubles, packed; a shuffle's scratch overlays it][tracked arrays: 84 ucap bytes]
     __shared__ double s_rec[R::N];
     __shared__ int s_mu[B];
+    __shared__ int s_mu2[2][B], s_cid2[2][B];      // table mode: two blocks in flight
+    __shared__ double s_h2[2][B];
     __shared__ double s_h[B];
     __shared__ Ctrl s_ctrl;
     __shared__ int s_w[2 * kCsWaves];
-    __shared__ int s_nmove, s_bad, s_nan, s_same;
+    __shared__ int s_nmove, s_bad, s_nan, s_same, s_nfail, s_task;
     __shared__ double s_tvrun;
     const int tid = threadIdx.x;
     const int64_t p = b.p;
@@ -148,11 +154,17 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     double q = ctl->q;
     const double q_floor = ctl->q_floor;
     // 100 MHz ticks per phase (thread 0's view): list, scan, exact gradients, visits, re-check, accept, bookkeeping, dropzeros!
-    uint64_t tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tdbg[4] = {0, 0, 0, 0}, tdm = 0;
+    auto dlap = [&](int ph) { const uint64_t now = __builtin_amdgcn_s_memrealtime(); tdbg[ph] += now - tdm; tdm = now; };
     uint64_t tmark = __builtin_amdgcn_s_memrealtime();
     const uint64_t cyc0 = __builtin_amdgcn_s_memtime(), tick0 = tmark;
     auto lap = [&](int ph) { const uint64_t now = __builtin_amdgcn_s_memrealtime(); tph[ph] += now - tmark; tmark = now; };
     int nnz = ctl->nnz, inject_count = ctl->inject_count;
+    const int tcap = ctl->tcap, fold_limit = ctl->fold_limit, full_cap = ctl->full_cap;
+    int ncid = ctl->ncid, tepoch = ctl->tepoch + 1;      // (gradients the table carried belong to the launch that carried them)
+    int64_t table_passes = 0, table_rows = 0, forced_rounds = 0;
+    int forced_rounds_here = 0;
+    bool forced_dirty = false;
     bool prev_conv = ctl->prev_conv != 0, conv = ctl->conv != 0;
     double* s_G = s_dynamic;
     CsTracked lt;                                 // the LDS copy of the tracked arrays
@@ -170,6 +182,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     for (int64_t k = tid; k < p; k += kCsThreads) { b.i2s[k] = 0; b.bfold[k] = b.beta[k]; b.inmoved[k] = 0; b.gxp[k] = -1; b.iota[k] = k; }
     for (int u = tid; u < ucap; u += kCsThreads) lt.iota[u] = u;
     if (tid == 0) {
+        s_nfail = 0;
         s_ctrl.lambda0 = lambda0; s_ctrl.n_total = n_total; s_ctrl.maxH = 0.0; s_ctrl.loss = loss; s_ctrl.has_omega = has_omega;
         s_ctrl.domain_error = 0; s_ctrl.pad = 0; s_ctrl.q_carry = q; s_ctrl.cert_abs = cert_abs;
     }
@@ -236,6 +249,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         if (cov_visits > cov_budget) { status = kCsRefresh; break; }
         if (sqrt_loss && q < q_floor) { status = kCsNeedQ; break; }      // r'r has run out of digits: the host sums it from r
         const bool full = conv;
+        if (full && nnz > full_cap) { status = kCsHostFull; break; }
         const uint64_t rng_before = rng;
         const int L = full ? (int)p : nnz;
         const int Lm1 = L > 0 ? L - 1 : 0;
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
 
         // ---- the scan: which positions are visited ("unsettled"), in visit order ----
         int cnt = 0, nocol = 0, nzero = 0, nsupp = 0, nexc = 0;
-        bool scanned = false;
+        bool scanned = false, want_fold = false;
         if (!full) {                     // an active pass visits its whole list: nothing to classify (unless a column is missing)
             int nc_mine = 0;
             for (int i = tid; i < L; i += kCsThreads) {
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             int nz_mine = 0, ns_mine = 0, nx_mine = 0;
             const double thr_base = lambda0 * (sqrt_loss ? sqrt(q) : n_total);
             for (int i0 = 0; i0 < L; i0 += kCsThreads * E) {
-                int k[E], sl[E], isl[E], inm[E];
+                int k[E], sl[E], isl[E], inm[E], frc[E];
                 bool valid[E], uns[E], nc[E], st[E];
                 double gk[E], bk[E], ak[E], om[E], mk[E];
 #pragma unroll
@@ -293,13 +307,13 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
 #pragma unroll
                 for (int e = 0; e < E; ++e) {                        // every load unconditional (clamped index): all in flight together
                     gk[e] = b.g[k[e]]; bk[e] = b.beta[k[e]]; sl[e] = b.slot[k[e]]; isl[e] = b.i2s[k[e]]; inm[e] = b.inmoved[k[e]];
-                    ak[e] = b.a[k[e]]; mk[e] = b.colmax[k[e]]; om[e] = has_omega ? b.omega[k[e]] : 1.0;
+                    ak[e] = b.a[k[e]]; mk[e] = b.colmax[k[e]]; om[e] = has_omega ? b.omega[k[e]] : 1.0; frc[e] = b.forced[k[e]];
                 }
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     // (a coordinate that has itself moved since the fold -- it left the support -- is never settled by the bound:
                     // M_k leaves out G_kk = a_k, by far the largest entry of its column)
-                    st[e] = valid[e] & full & (bk[e] == 0.0) & (ak[e] > 0.0) & (inm[e] == 0) &
+                    st[e] = valid[e] & full & (bk[e] == 0.0) & (ak[e] > 0.0) & (inm[e] == 0) & (frc[e] == 0) &
                             (fabs(gk[e]) + mk[e] * TV0 <= thr_base * om[e] * (1.0 - 1e-9) - cert_abs * sqrt(ak[e]));
                     uns[e] = valid[e] & !st[e];
                     nc[e] = uns[e] & (sl[e] < 0);
@@ -324,9 +338,14 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             nexc = cs_block_sum(nx_mine, s_w);
             // many inactive coordinates fail the bound only because it has grown loose -- or one without a Gram column does,
             // which would send the host for a pass over X: fold (exact g for everybody) and look again
-            if (attempt == 0 && nmoved > 0 && ((full && cnt - nsupp > kCsNearMax) || nocol > 0)) { fold(); pass_id += 2; continue; }
+            if (attempt == 0 && nmoved > 0 && ((full && cnt - nsupp > kCsNearMax) || nocol > 0)) {
+                if (nmoved > fold_limit) { want_fold = true; break; }      // p x moves gathers: the chip does that, not one CU
+                fold(); pass_id += 2; tepoch += 1;
+                continue;
+            }
             break;
         }
+        if (want_fold) { status = kCsNeedFold; rng = rng_before; break; }
         if (nocol > 0) {                 // coordinates about to be visited without a Gram column: the host fetches them
             status = nocol > busy_limit ? kCsBusy : kCsNeedColumns; n_list = nocol; rng = rng_before;
             break;
@@ -337,16 +356,47 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         // kept current there, else g - sum_m pend_m G_m), their Gram block ----
         stage_pending();
         const bool in_lds = cnt <= ucap;
+        const bool table = !in_lds;      // a visit list beyond the LDS-sized Gram block: the Gram TABLE in device memory (see k_cov_solve's header)
+        if (table && cnt > tcap) { status = kCsOutgrown; rng = rng_before; break; }
         const CsTracked T = in_lds ? lt : gt;
         if (tid == 0) s_same = (in_lds && cnt == cnt_prev) ? 1 : 0;
         __syncthreads();
+        int nnew = 0;
+        if (table) {                     // every visited coordinate gets a table id; those new to the table are listed (newc: their positions)
+            for (int again = 0; again < 2; ++again) {
+                nnew = 0;
+                for (int u0 = 0; u0 < cnt; u0 += kCsThreads) {
+                    const int u = u0 + tid;
+                    const bool in = u < cnt;
+                    const int cidv = b.cidof[b.uk[in ? u : 0]];
+                    const bool neu[1] = {in && cidv < 0};
+                    int at[1];
+                    const int tot = cs_rank<1>(neu, at, s_w);
+                    if (in) b.ucid[u] = neu[0] ? ncid + nnew + at[0] : cidv;
+                    if (neu[0]) b.newc[nnew + at[0]] = u;
+                    nnew += tot;
+                }
+                if (ncid + nnew <= tcap) break;
+                for (int c = tid; c < ncid; c += kCsThreads) b.cidof[b.cidk[c]] = -1;      // the table is full: it starts over with this list
+                __syncthreads();
+                ncid = 0; tepoch += 1;
+            }
+            __syncthreads();
+            for (int i = tid; i < nnew; i += kCsThreads) { const int64_t k = b.uk[b.newc[i]]; b.cidof[k] = ncid + i; b.cidk[ncid + i] = k; b.gxe[ncid + i] = tepoch - 1; }
+            __syncthreads();
+        }
         for (int u = tid; u < cnt; u += kCsThreads) {
             const int64_t k = b.uk[u];
             const int gp = b.gxp[k];
             const double bk = b.beta[k], gxk = b.gx[k], omk = has_omega ? b.omega[k] : 1.0;
             const int64_t vo = (int64_t)b.slot[k] * p, kprev = b.uprev[u];
             T.k[u] = k; T.voff[u] = vo; T.beta[u] = bk; T.om[u] = omk;
-            T.gx[u] = (gp == pass_id - 1) ? gxk : exact_g(k);
+            if (table) {                 // the table carries the exact gradient of every coordinate it holds through all the moves of table-mode passes
+                const int c = b.ucid[u];
+                if (b.gxe[c] != tepoch) { b.gxc[c] = (gp == pass_id - 1) ? gxk : exact_g(k); b.gxe[c] = tepoch; }
+            } else {
+                T.gx[u] = (gp == pass_id - 1) ? gxk : exact_g(k);
+            }
             if (kprev != k) s_same = 0;
         }
         if (tid == 0) { s_ctrl.maxH = 0.0; s_ctrl.domain_error = 0; s_ctrl.q_carry = q; s_bad = 0; s_nan = 0; s_tvrun = 0.0; }
@@ -356,25 +406,62 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             for (int e = tid; e < cnt * cnt; e += kCsThreads) { const int i = e / cnt, j = e - i * cnt; if (i <= j) s_G[cs_tri(i, j, cnt)] = b.Gcols[T.voff[j] + T.k[i]]; }
             for (int u = tid; u < cnt; u += kCsThreads) b.uprev[u] = T.k[u];
             cnt_prev = cnt;
-        } else if (!in_lds) {
+        } else if (table) {
             cnt_prev = -1;
+            // rows and columns of the coordinates new to the table: Gc[a][c] = Gc[c][a] = (column of a)[k_c], c <= a.  Four rows at a time
+            // (the coordinates of the table's ids staged in the LDS the Gram block of small lists would use): 16 gathers in flight per thread
+            const int ntot = ncid + nnew;
+            int32_t* s_kc = reinterpret_cast<int32_t*>(s_dynamic);
+            const int kc_room = (int)(cs_tri_doubles((size_t)ucap) * 2);
+            const bool staged = ntot <= kc_room;
+            if (nnew > 0 && staged) for (int c = tid; c < ntot; c += kCsThreads) s_kc[c] = (int32_t)b.cidk[c];
+            __syncthreads();
+            for (int i0 = 0; i0 < nnew; i0 += 4) {
+                int64_t off[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) off[r] = T.voff[b.newc[min(i0 + r, nnew - 1)]];
+                for (int c0 = 0; c0 < ntot; c0 += 4 * kCsThreads) {
+                    double v[4][4];
+                    int kc[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const int c = min(c0 + e * kCsThreads + tid, ntot - 1); kc[e] = staged ? s_kc[c] : (int32_t)b.cidk[c]; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[r][e] = b.Gcols[off[r] + kc[e]];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int c = c0 + e * kCsThreads + tid, a = ncid + i0 + r;
+                            if (i0 + r < nnew && c <= a) { b.Gc[(size_t)a * tcap + c] = v[r][e]; b.Gc[(size_t)c * tcap + a] = v[r][e]; }
+                        }
+                }
+            }
+            table_rows += nnew; table_passes += 1;
+            ncid = ntot;
+            __syncthreads();
+            cnt_prev = -1;               // (the staging overwrote the LDS Gram block)
         }
         __syncthreads();
         lap(2);
 
         // ---- _cdPass! over the visit list, 64 visits at a time: k_cov_block's gather, gram_scalar_body's B sequential updates
         // (on the tracked arrays: `beta` and `omega` indexed by position, the identity as the block's coordinate list) ----
-        for (int j0 = 0; j0 < cnt; j0 += B) {
+        if (in_lds) for (int j0 = 0; j0 < cnt; j0 += B) {
             const int nb = min(B, cnt - j0);
+            tdm = __builtin_amdgcn_s_memrealtime();
             for (int e = tid; e < B * B; e += kCsThreads) {
                 const int sI = e / B, j = e % B;
-                if (sI <= j && j < nb) s_rec[R::g(sI, j)] = in_lds ? s_G[cs_tri(j0 + sI, j0 + j, cnt)] : b.Gcols[T.voff[j0 + j] + T.k[j0 + sI]];
+                if (sI <= j && j < nb) s_rec[R::g(sI, j)] = s_G[cs_tri(j0 + sI, j0 + j, cnt)];
             }
             if (tid < B) s_rec[R::OFF_C + tid] = (tid < nb) ? T.gx[j0 + tid] : 0.0;
             if (tid == 0) s_rec[R::OFF_Q] = s_ctrl.q_carry;
             __syncthreads();
+            dlap(0);
             if (tid < 64) {
                 gram_scalar_body<4>(s_rec, nb, 0, &s_ctrl, T.beta, T.om, T.iota, T.hs, T.nv, T.tch, j0, T.qs, tid);
+                dlap(1);
                 // the block's moves, compacted (k_cov_gupdate's prologue), and the total variation after each visit
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -393,14 +480,142 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 if (tid == 0) s_tvrun = base + last;
             }
             __syncthreads();
+            dlap(2);
             const int nmove = s_nmove;
             if (nmove > 0)               // every tracked coordinate sees the block's moves (the block's own members too: gx stays current)
                 for (int u = tid; u < cnt; u += kCsThreads) {
                     double acc = T.gx[u];
-                    if (in_lds) { for (int i = 0; i < nmove; ++i) { const int mv = s_mu[i]; acc = fma(-s_h[i], s_G[cs_tri(min(mv, u), max(mv, u), cnt)], acc); } }
-                    else { const int64_t k = T.k[u]; for (int i = 0; i < nmove; ++i) acc = fma(-s_h[i], b.Gcols[T.voff[s_mu[i]] + k], acc); }
+                    for (int i = 0; i < nmove; ++i) { const int mv = s_mu[i]; acc = fma(-s_h[i], s_G[cs_tri(min(mv, u), max(mv, u), cnt)], acc); }
                     T.gx[u] = acc;
                 }
+            __syncthreads();
+            dlap(3);
+        }
+        if (table && cnt > 0) {
+            // Table mode, two blocks in flight.  The update of the table's gradients with a block's moves (64 rows of Gc, ~400 KB at 800
+            // coordinates: the L1 of one CU moves that in ~4 us, as long as the block's 64 visits take) runs on waves 1-3 WHILE wave 0 visits
+            // the next block; that block's own 64 gradients get the moves first (a 64 x 64 tile of Gc, summed in the same order: bit for bit
+            // what the rows will leave in gxc), and its Gram block was gathered during the block before.  Per block: tile + visits instead
+            // of gather + visits + rows (13.6 -> ~8 us at benchmark/cd_bench.jl's shape).
+            const int nch = (cnt + B - 1) / B;
+            auto recb = [&](int which) -> double* { return which ? s_dynamic : s_rec; };
+            static_assert(R::N <= 2688, "the second block record");
+            double* s_tile = s_dynamic + 2688;                   // [64 moves][64 ids] of the block about to be visited
+            const int lane_t = tid & 63, part = tid >> 6;
+            double gv[B * B / kCsThreads];
+            auto gather_block = [&](int jb) {                    // Gc[id_j][id_sI] of block jb for this thread's 16 (sI, j) pairs: all in flight
+                const int cj = b.ucid[min(jb + lane_t, cnt - 1)];
+                int ci[B * B / kCsThreads];
+#pragma unroll
+                for (int t = 0; t < B * B / kCsThreads; ++t) ci[t] = b.ucid[min(jb + part + 4 * t, cnt - 1)];
+#pragma unroll
+                for (int t = 0; t < B * B / kCsThreads; ++t) gv[t] = b.Gc[(size_t)cj * tcap + ci[t]];
+            };
+            auto store_block = [&](double* rec, int nbn) {
+#pragma unroll
+                for (int t = 0; t < B * B / kCsThreads; ++t) { const int sI = part + 4 * t; if (sI <= lane_t && lane_t < nbn) rec[R::g(sI, lane_t)] = gv[t]; }
+            };
+            auto rows_update = [&](const double* hb, const int* mub, int nmv) {   // gxc -= sum_i h_i Gc[mu_i][.], moves in visit order
+                // 256 ids at a time per wave, handed out by a counter: the waves that only move memory start at once, wave 0 joins after its visits
+                for (;;) {
+                    int task = 0;
+                    if (lane_t == 0) task = atomicAdd(&s_task, 1);
+                    task = __builtin_amdgcn_readfirstlane(task);
+                    if (task * 256 >= ncid) break;
+                    const int c0 = task * 256 + 4 * lane_t;
+                    if (c0 >= ncid) continue;
+                    double4 acc = *reinterpret_cast<const double4*>(b.gxc + c0);
+                    int i = 0;
+                    for (; i + 16 <= nmv; i += 16) {
+                        double4 rv[16];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) rv[t] = *reinterpret_cast<const double4*>(b.Gc + (size_t)mub[i + t] * tcap + c0);
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            const double hv = -hb[i + t];
+                            acc.x = fma(hv, rv[t].x, acc.x); acc.y = fma(hv, rv[t].y, acc.y); acc.z = fma(hv, rv[t].z, acc.z); acc.w = fma(hv, rv[t].w, acc.w);
+                        }
+                    }
+                    for (; i + 4 <= nmv; i += 4) {
+                        double4 rv[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) rv[t] = *reinterpret_cast<const double4*>(b.Gc + (size_t)mub[i + t] * tcap + c0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const double hv = -hb[i + t];
+                            acc.x = fma(hv, rv[t].x, acc.x); acc.y = fma(hv, rv[t].y, acc.y); acc.z = fma(hv, rv[t].z, acc.z); acc.w = fma(hv, rv[t].w, acc.w);
+                        }
+                    }
+                    for (; i < nmv; ++i) {
+                        const double4 rv = *reinterpret_cast<const double4*>(b.Gc + (size_t)mub[i] * tcap + c0);
+                        const double hv = -hb[i];
+                        acc.x = fma(hv, rv.x, acc.x); acc.y = fma(hv, rv.y, acc.y); acc.z = fma(hv, rv.z, acc.z); acc.w = fma(hv, rv.w, acc.w);
+                    }
+                    *reinterpret_cast<double4*>(b.gxc + c0) = acc;       // (ids beyond ncid up to the next multiple of four: scratch nobody reads)
+                }
+            };
+            if (tid < B) s_cid2[0][tid] = b.ucid[min(tid, cnt - 1)];
+            gather_block(0);
+            store_block(recb(0), min(B, cnt));
+            __syncthreads();
+            int pend_n = 0;                                       // moves of the block before, not yet in gxc
+            for (int ch = 0; ch < nch; ++ch) {
+                const int par = ch & 1, j0 = ch * B, nb = min(B, cnt - j0);
+                double* rec = recb(par);
+                const int* cid_cur = s_cid2[par];
+                const double* hprev = s_h2[par ^ 1];
+                const int* muprev = s_mu2[par ^ 1];
+                tdm = __builtin_amdgcn_s_memrealtime();
+                // (A) this block's gradients: gxc as the rows left it, then the moves of the block before, in visit order
+                if (pend_n > 0) {
+                    double tv_[B / kCsWaves];
+#pragma unroll
+                    for (int r = 0; r < B / kCsWaves; ++r) tv_[r] = b.Gc[(size_t)muprev[min(part + kCsWaves * r, pend_n - 1)] * tcap + cid_cur[lane_t]];
+#pragma unroll
+                    for (int r = 0; r < B / kCsWaves; ++r) s_tile[(part + kCsWaves * r) * B + lane_t] = tv_[r];
+                    __syncthreads();
+                }
+                if (tid < B) {
+                    double v = b.gxc[cid_cur[tid]];
+                    for (int i = 0; i < pend_n; ++i) v = fma(-hprev[i], s_tile[i * B + tid], v);
+                    rec[R::OFF_C + tid] = tid < nb ? v : 0.0;
+                }
+                if (tid == 0) { rec[R::OFF_Q] = s_ctrl.q_carry; s_task = 0; }
+                __syncthreads();
+                dlap(0);
+                // (B) wave 0 visits; the others bring gxc up to date with the block before; everybody has the next block's Gram entries on the way
+                const bool more = ch + 1 < nch;
+                if (more) gather_block(j0 + B);
+                if (more && part == 1) s_cid2[par ^ 1][lane_t] = b.ucid[min(j0 + B + lane_t, cnt - 1)];
+                if (tid < 64) {
+                    gram_scalar_body<4>(rec, nb, 0, &s_ctrl, T.beta, T.om, T.iota, T.hs, T.nv, T.tch, j0, T.qs, tid);
+                    dlap(1);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const double hv = tid < nb ? T.hs[j0 + tid] : 0.0;
+                    const bool nz = hv != 0.0;                       // (a NaN h counts as a move: the pass is then undone)
+                    const unsigned long long mask = __ballot(nz);
+                    if (nz) { const int at = __popcll(mask & ((1ull << tid) - 1ull)); s_h2[par][at] = hv; s_mu2[par][at] = cid_cur[tid]; }
+                    if (__ballot(hv != hv)) { if (tid == 0) s_nan = 1; }
+                    double run = (hv == hv) ? fabs(hv) : 0.0;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(run, off, 64); if (tid >= off) run += o; }
+                    const double base = s_tvrun;
+                    if (tid < nb) T.tv[j0 + tid] = base + run;
+                    if (tid == 0) s_nmove = __popcll(mask);
+                    const double last = __shfl(run, 63, 64);
+                    if (tid == 0) s_tvrun = base + last;
+                    dlap(2);
+                }
+                if (pend_n > 0) rows_update(hprev, muprev, pend_n);
+                if (more) store_block(recb(par ^ 1), min(B, cnt - j0 - B));
+                __syncthreads();
+                dlap(3);
+                pend_n = s_nmove;
+            }
+            if (tid == 0) s_task = 0;
+            __syncthreads();
+            if (pend_n > 0) rows_update(s_h2[(nch - 1) & 1], s_mu2[(nch - 1) & 1], pend_n);
             __syncthreads();
         }
         // what the p-sized loops below read by position: in global memory
@@ -416,7 +631,6 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
 
         // ---- the settled positions, re-checked with the bound as it stood at their turn; exactly where the bound fails ----
         if (full && cnt < L && (tv_pass > 0.0 || TV0 > 0.0)) {
-            int nexact = 0;
             const int cm1 = cnt > 0 ? cnt - 1 : 0;
             for (int64_t k0 = 0; k0 < p; k0 += kCsThreads * E) {
                 int64_t k[E];
@@ -441,22 +655,64 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     const double qk = vbk[e] > 0 ? qsb[e] : q_start;
                     const double cert = lambda0 * (sqrt_loss ? sqrt(qk) : n_total) * om[e] * (1.0 - 1e-9) - cert_abs * sqrt(ak[e]);
                     const bool fails = chk[e] & (sf[e] != 0) & !(fabs(gk[e]) + mk[e] * tvk <= cert);
-                    if (fails) {                                  // (rare) the exact gradient when its turn came
-                        double acc = exact_g(k[e]);
-                        for (int i = 0; i < vbk[e]; ++i) { const double hv = b.hs[i]; if (hv != 0.0) acc = fma(-hv, b.Gcols[b.voff[i] + k[e]], acc); }
-                        nexact += 1;
-                        if (!(fabs(acc) <= cert)) s_bad = 1;
+                    if (fails) {                                  // listed: the exact gradient when its turn came is a gather the block shares
+                        const int at = atomicAdd(&s_nfail, 1);
+                        b.holes[at] = (int32_t)k[e]; b.fills[at] = vbk[e]; b.bsnap[at] = cert;
                     }
                 }
             }
-            exact_rechecks += nexact;                             // (this thread's; summed at the end)
+            __syncthreads();
+            // g_k - sum_(pending) pend_m G_mk - sum_(visits before its turn) h_i G_ik: one listed coordinate per wave, its terms over the lanes
+            const int nfail = s_nfail;
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int f = wave; f < nfail; f += kCsWaves) {
+                const int64_t kf = b.holes[f];
+                const int vf = b.fills[f];
+                double part = 0.0;
+                for (int m0 = lane; m0 < nmoved; m0 += 256) {
+                    double gv[4], pv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { const int m = min(m0 + 64 * t, nmoved - 1); gv[t] = b.Gcols[b.poff[m] + kf]; pv[t] = (m0 + 64 * t < nmoved) ? b.pendv[m] : 0.0; }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) part = fma(-pv[t], gv[t], part);
+                }
+                for (int i0 = lane; i0 < vf; i0 += 256) {
+                    double gv[4], hv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { const int i = min(i0 + 64 * t, vf - 1); gv[t] = b.Gcols[b.voff[i] + kf]; hv[t] = (i0 + 64 * t < vf) ? b.hs[i] : 0.0; }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) part = fma(-hv[t], gv[t], part);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+                const double acc = b.g[kf] + part;
+                if (lane == 0 && !(fabs(acc) <= b.bsnap[f])) { s_bad = 1; b.forced[kf] = 1; }
+            }
+            if (tid == 0) exact_rechecks += nfail;
         }
         __syncthreads();
-        bool undo = s_bad != 0 || s_nan != 0 || (nzero > 0 && (TV0 > 0.0 || tv_pass > 0.0));
-        if (full && cnt > 0 && inject_every > 0) { inject_count += 1; if (inject_count % inject_every == 0) undo = true; }
-        if (undo) {                       // the pass never happened (beta itself was not touched): the host walks it the careful way
-            status = kCsRollback; rng = rng_before;
+        if (tid == 0) s_nfail = 0;
+        const bool crossed = s_bad != 0;
+        bool undo = crossed || s_nan != 0 || (nzero > 0 && (TV0 > 0.0 || tv_pass > 0.0));
+        bool injected = false;
+        if (full && cnt > 0 && inject_every > 0) { inject_count += 1; if (inject_count % inject_every == 0) { undo = true; injected = true; } }
+        if (undo) {                       // the pass never happened (beta itself was not touched)
+            rng = rng_before;
+            // coordinates that crossed their threshold through the pass's own moves: the same pass again with those on the visit list
+            // (visiting more than necessary is always right); after a few such rounds, or for anything else, the host walks it the careful way
+            if (crossed && !injected && s_nan == 0 && !(nzero > 0 && (TV0 > 0.0 || tv_pass > 0.0)) && forced_rounds_here < kCsForcedRounds) {
+                forced_rounds_here += 1; forced_rounds += 1; forced_dirty = true;
+                tepoch += 1;              // (the table's gradients have seen the undone moves)
+                __syncthreads();
+                continue;
+            }
+            status = kCsRollback;
             break;
+        }
+        forced_rounds_here = 0;
+        if (forced_dirty && full) {       // the marks have served
+            for (int64_t k = tid; k < p; k += kCsThreads) b.forced[k] = 0;
+            forced_dirty = false;
         }
         lap(4);
 
@@ -471,10 +727,11 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             int at[1];
             const int tot = cs_rank<1>(neu, at, s_w);
             if (neu[0]) { b.moved[nmoved + at[0]] = (int32_t)k; b.inmoved[k] = 1; }
-            if (in) { b.gxp[k] = pass_id; b.gx[k] = T.gx[u]; b.beta[k] = T.beta[u]; }
+            if (in) { b.gxp[k] = pass_id; b.gx[k] = table ? b.gxc[b.ucid[u]] : T.gx[u]; b.beta[k] = T.beta[u]; }
             nmoved += tot;
         }
         pass_id += 1;
+        if (in_lds) tepoch += 1;          // (the table's gradients have not seen this pass's moves)
         TV0 += tv_pass; q = q_end;
         __syncthreads();
         lap(5);
@@ -647,6 +904,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
 
     // ---- what the host needs: the support in slot order with its values, the moves still pending on g ----
     __syncthreads();
+    if (forced_dirty) for (int64_t k = tid; k < p; k += kCsThreads) b.forced[k] = 0;
     for (int s = tid; s < nnz; s += kCsThreads) { const int k = b.s2i[s]; b.out_sup_idx[s] = k; b.out_sup_val[s] = b.beta[k]; }
     for (int m = tid; m < nmoved; m += kCsThreads) { const int km = b.moved[m]; b.out_moved_idx[m] = km; b.out_moved_val[m] = b.beta[km] - b.bfold[km]; }
     {   // exact re-checks were counted per thread
@@ -659,12 +917,14 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     }
     if (tid == 0) {
         ctl->rng = rng; ctl->q = q; ctl->nnz = nnz; ctl->prev_conv = prev_conv ? 1 : 0; ctl->conv = conv ? 1 : 0;
+        ctl->ncid = ncid; ctl->tepoch = tepoch; ctl->table_passes = table_passes; ctl->table_rows = table_rows; ctl->forced_rounds = forced_rounds;
         ctl->inject_count = inject_count; ctl->status = status; ctl->n_list = n_list; ctl->n_moved = nmoved;
         ctl->domain_error = dom_any; ctl->passes = passes; ctl->full_passes = full_passes; ctl->visits = visits;
         ctl->cov_visits = cov_visits; ctl->cov_visits_full = cov_visits_full; ctl->settled = settled_total; ctl->folds = folds; ctl->exact_rechecks = exact_rechecks;
         ctl->maxH = lastH;
         lap(7);
         for (int i = 0; i < 8; ++i) ctl->ticks[i] = (int64_t)tph[i];
+        for (int i = 0; i < 4; ++i) ctl->dbg[i] = (int64_t)tdbg[i];
         ctl->cycles = (int64_t)(__builtin_amdgcn_s_memtime() - cyc0); ctl->ticks_total = (int64_t)(__builtin_amdgcn_s_memrealtime() - tick0);
     }
 }
@@ -681,6 +941,7 @@ __global__ __launch_bounds__(256) void k_cov_colmax(double* __restrict__ colmax,
 enum { kCsNotNow = 0, kCsFinished = 1, kCsAgain = 2 };
 
 inline size_t cs_align(size_t v) { return (v + 255) / 256 * 256; }
+inline int cs_env_int(const char* nm, int dflt) { const char* v = getenv(nm); return v ? atoi(v) : dflt; }
 
 // scratch of the kernel (122 p bytes of device memory) and the pinned block it reads the support from and writes its
 // results into (zero-copy, as the one-launch solve's: nothing is copied around the launch)
@@ -688,7 +949,9 @@ int32_t cs_alloc(cdh_handle h) {
     GradCache& c = h->gc;
     if (c.cs_dev || !c.cs_enabled) return CDH_OK;
     const size_t p = (size_t)h->p;
-    const size_t dev_bytes = 11 * cs_align(8 * p) + 5 * cs_align(8 * p) + 12 * cs_align(4 * p) + 2 * cs_align(p) + cs_align(8 * p) /* colmax */;
+    const size_t tc = (size_t)kCsTableCap;
+    const size_t dev_bytes = 11 * cs_align(8 * p) + 5 * cs_align(8 * p) + 12 * cs_align(4 * p) + 3 * cs_align(p) + cs_align(8 * p) /* colmax */ +
+                             cs_align(8 * tc * tc) + 2 * cs_align(8 * tc) + cs_align(4 * tc) + 3 * cs_align(4 * p) /* the Gram table */;
     const size_t pin_bytes = cs_align(sizeof(CovSolveCtl)) + 4 * cs_align(4 * p) + 2 * cs_align(8 * p);
     void* dev_view = nullptr;
     bool fits = hipMalloc((void**)&c.cs_dev, dev_bytes) == hipSuccess && hipHostMalloc((void**)&c.cs_pin, pin_bytes) == hipSuccess &&
@@ -713,9 +976,13 @@ int32_t cs_alloc(cdh_handle h) {
     b.touched = (int32_t*)take(4 * p); b.s2i = (int32_t*)take(4 * p); b.i2s = (int32_t*)take(4 * p); b.list = (int32_t*)take(4 * p);
     b.vb = (int32_t*)take(4 * p); b.moved = (int32_t*)take(4 * p); b.holes = (int32_t*)take(4 * p); b.fills = (int32_t*)take(4 * p);
     b.gxp = (int32_t*)take(4 * p); b.upos = (int32_t*)take(4 * p); b.aidx = (int32_t*)take(4 * p); b.occ = (int32_t*)take(4 * p);
-    b.setflag = (uint8_t*)take(p); b.inmoved = (uint8_t*)take(p);
+    b.setflag = (uint8_t*)take(p); b.inmoved = (uint8_t*)take(p); b.forced = (uint8_t*)take(p);
+    if (hipMemset(b.forced, 0, p) != hipSuccess) return fail(h, CDH_HIP_ERROR, "hipMemset (the device loop's marks)");
     c.d_colmax = (double*)take(8 * p);
     b.colmax = c.d_colmax;
+    b.Gc = (double*)take(8 * tc * tc); b.gxc = (double*)take(8 * tc); b.cidk = (int64_t*)take(8 * tc); b.gxe = (int32_t*)take(4 * tc);
+    b.cidof = (int32_t*)take(4 * p); b.ucid = (int32_t*)take(4 * p); b.newc = (int32_t*)take(4 * p);
+    c.cs_ncid = 0; c.cs_table_reset = true;
     // the pinned block, as the host and as the device address it
     size_t o = cs_align(sizeof(CovSolveCtl));
     auto pin = [&](size_t bytes) { const size_t at = o; o += cs_align(bytes); return at; };
@@ -800,10 +1067,26 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
         const size_t budget = c.cs_lds_budget ? c.cs_lds_budget : kCsLdsBudget;
         while (ucap > 8 && 8 * cs_tri_doubles((size_t)ucap) + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > budget) ucap -= 4;
     }
-    const int64_t support_cap = ucap - kCsTrackedMargin;
+    // (visit lists beyond that run in the kernel's table mode, up to the table's rows; CDH_CS_TABLE=0: they stay with the host)
+    static const bool table_on = cs_env_int("CDH_CS_TABLE", 1) != 0;
+    const int64_t support_cap = table_on ? kCsTableCap - kCsTableMargin : ucap - kCsTrackedMargin;
     if (h->x.nnz() > support_cap) return not_now();
     CHK(cs_alloc(h));
     if (!c.cs_enabled) return not_now();
+    // Full passes of large supports stay with the host's device pass (gc_pass_device): certifying the inactive coordinates takes g
+    // for all p after every block of moves -- p x moves gathers per pass, which twenty workgroups do in microseconds and one does not
+    // (the bound of the loop's certificates is useless there: M_k TV exceeds the thresholds themselves once hundreds of coordinates move)
+    static const int full_env = cs_env_int("CDH_CS_FULL_CAP", 0);
+    const int32_t full_cap = full_env > 0 ? full_env : ucap - kCsTrackedMargin;
+    if (full && h->x.nnz() > full_cap) return not_now();
+    if (c.cs_table_reset) {          // a new X: the table's entries are void
+        HIPCHK(h, hipMemsetAsync(c.cs_bufs.cidof, 0xff, sizeof(int32_t) * (size_t)h->p, h->stream));
+        c.cs_ncid = 0; c.cs_table_reset = false;
+    }
+    // a fold is p x (pending moves) gathers: beyond a few moves the chip does it (gc_fold's kernel), not the one workgroup of the loop
+    static const int fold_env = cs_env_int("CDH_CS_FOLD_LIMIT", 0);
+    const int32_t fold_limit = fold_env > 0 ? fold_env : (int32_t)std::max<int64_t>(16, 120000 / h->p);
+    if ((int64_t)c.moved.size() > fold_limit) gc_fold(h);
     if (!c.slot_dev_ok) {             // the columns were dropped since the map last went down (a new X): the kernel asks d_slot who has one
         HIPCHK(h, hipMemcpyAsync(c.d_slot, c.slot.data(), sizeof(int32_t) * (size_t)h->p, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -823,7 +1106,8 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
         if (!(c.mode == 3 || gc_short_columns(h))) lim = std::min<int64_t>(lim, h->n_total / gc_rows_per_nnz(h));
         ctl.nnz_limit = (int32_t)std::min<int64_t>({lim, support_cap, (int64_t)0x7fffffff});
     }
-    ctl.busy_limit = kGcBusy; ctl.inject_every = c.inject_rollback; ctl.pad0 = ctl.pad1 = 0;
+    ctl.busy_limit = kGcBusy; ctl.inject_every = c.inject_rollback; ctl.fold_limit = fold_limit;
+    ctl.tcap = table_on ? kCsTableCap : 0; ctl.ncid = c.cs_ncid; ctl.tepoch = c.cs_tepoch; ctl.full_cap = full_cap; ctl.pad0 = 0;
     ctl.rng = sched.state(); ctl.q = c.q; ctl.q_floor = h->loss == CDH_SQRT ? kGcQGuard * c.q_exact : 0.0;
     ctl.nnz = (int32_t)h->x.nnz(); ctl.prev_conv = *prev_conv ? 1 : 0; ctl.conv = *conv ? 1 : 0; ctl.inject_count = c.inject_count;
     ctl.status = -1; ctl.n_list = 0;
@@ -835,7 +1119,9 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     // the tracked coordinates' Gram block (8 u^2 bytes) and arrays (kCsTrackedBytes u, rounded up) next to the shuffle's
     ucap = kCsUcapMax;
     while (ucap > 8 && 8 * cs_tri_doubles((size_t)ucap) + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes > c.cs_lds_budget) ucap -= 4;
-    if (h->x.nnz() > ucap - kCsTrackedMargin) return not_now();     // (the budget the runtime really granted is smaller)
+    // (table mode keeps a second block record and a 64 x 64 tile where the LDS Gram block of small lists would be: kCsTableLds doubles)
+    if (cs_tri_doubles((size_t)ucap) < kCsTableLds) ctl.tcap = 0;
+    if (ctl.tcap == 0 && h->x.nnz() > ucap - kCsTrackedMargin) return not_now();     // (the budget the runtime really granted is smaller)
     const unsigned lds = (unsigned)(8 * cs_tri_doubles((size_t)ucap) + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes);
     if (o->randomize && 24 * ((size_t)h->p + 1) > (size_t)lds) return not_now();   // the shuffle's scratch overlays the dynamic LDS
     hipLaunchKernelGGL(k_cov_solve, dim3(1), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
@@ -875,12 +1161,15 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
         c.dbeta[(size_t)k] = v;
         if (!c.in_moved[(size_t)k]) { c.in_moved[(size_t)k] = 1; c.moved.push_back(k); }
     }
+    c.cs_ncid = ctl.ncid; c.cs_tepoch = ctl.tepoch; c.n_cs_table_passes += ctl.table_passes; c.n_cs_table_rows += ctl.table_rows;
+    c.n_cs_forced_rounds += ctl.forced_rounds;
     if (ctl.folds > 0) c.g_host_ok = false;
     if (h->loss == CDH_SQRT) c.q = ctl.q;
     c.inject_count = ctl.inject_count;
     c.n_passes += ctl.full_passes; c.n_dev_passes += ctl.full_passes; c.n_certified += ctl.settled;
     c.n_cov += ctl.cov_visits; c.cov_since_ref += ctl.cov_visits; c.n_cs_passes += ctl.passes; c.n_cs_folds += ctl.folds; c.n_cs_exact += ctl.exact_rechecks;
     for (int i = 0; i < 8; ++i) c.cs_ticks[i] += ctl.ticks[i];
+    for (int i = 0; i < 4; ++i) c.cs_dbg[i] += ctl.dbg[i];
     c.cs_cycles += ctl.cycles; c.cs_ticks_total += ctl.ticks_total;
     c.n_exact += ctl.cov_visits_full;
     if (ctl.domain_error) h->domain_error = true;
@@ -896,6 +1185,8 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     case kCsOutgrown: return CDH_OK;                                // gc_prepare_full / gc_ready_for_cov draw the consequences
     case kCsRefresh: CHK(gc_rereference(h)); *outcome = kCsAgain; return CDH_OK;
     case kCsNeedQ: c.q_valid = false; CHK(gc_ensure_q(h)); *outcome = kCsAgain; return CDH_OK;
+    case kCsNeedFold: gc_fold(h); *outcome = kCsAgain; return CDH_OK;
+    case kCsHostFull: return CDH_OK;                                // the next (full) pass runs the pass-by-pass way
     case kCsBusy:     // many inactive coordinates about to move: back off (1, 2, 4 ... 16 plain passes), as gc_pass_device does
         c.cooldown = c.backoff; c.backoff = std::min(16, 2 * c.backoff);
         gc_invalidate(h, false);

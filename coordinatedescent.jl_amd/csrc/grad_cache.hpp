@@ -95,7 +95,7 @@ int32_t gc_dev_reserve(cdh_handle h, int64_t have) {
                hipMalloc((void**)&c.d_pass_idx, sizeof(int64_t) * (size_t)h->cap) == hipSuccess &&
                hipMalloc((void**)&c.d_pos_of, sizeof(int32_t) * (size_t)p) == hipSuccess &&
                hipMalloc((void**)&c.d_scanbuf, sizeof(int32_t) * (size_t)(h->cap + 4)) == hipSuccess &&
-               hipMalloc((void**)&c.d_setflag, (size_t)p) == hipSuccess &&
+               hipMalloc((void**)&c.d_setflag, 2 * (size_t)p) == hipSuccess &&       // [settled flags][forced marks]
                hipMalloc((void**)&c.d_pack, sizeof(double) * (size_t)(kPackHead + 3 * h->cap)) == hipSuccess &&
                hipHostMalloc((void**)&c.h_scanbuf, sizeof(int32_t) * (size_t)(h->cap + 4)) == hipSuccess &&
                hipHostMalloc((void**)&c.h_pack, sizeof(double) * (size_t)(kPackHead + 3 * h->cap)) == hipSuccess;
@@ -105,6 +105,8 @@ int32_t gc_dev_reserve(cdh_handle h, int64_t have) {
         c.d_scan = reinterpret_cast<cdk::CovScanOut*>(c.d_scanbuf); c.d_upos = c.d_scanbuf + 4;
         c.h_scan = reinterpret_cast<cdk::CovScanOut*>(c.h_scanbuf); c.h_upos = c.h_scanbuf + 4;
         HIPCHK(h, hipMemsetAsync(c.d_qs, 0, sizeof(double) * (size_t)h->cap, h->stream));
+        HIPCHK(h, hipMemsetAsync(c.d_setflag, 0, 2 * (size_t)p, h->stream));
+        c.d_forced = c.d_setflag + p; c.forced_dirty = false;
         c.g_dev_ok = false; c.a_dev_ok = false;
     }
     if (have > c.dev_slots_cap) {   // grow the store (64 columns at a time, at most kGcMaxBytes), keeping what is there
@@ -276,7 +278,7 @@ template <int NG> int32_t launch_cov_chunk(cdh_handle h, int m, bool chk = false
         if (chk)
             hipLaunchKernelGGL(k_cov_gupdate_chk, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot,
                                c.d_a, h->omega, h->d_ctrl, h->p, h->d_idx, h->d_hs, c.d_qs, c.d_upos, c.d_pos_of, c.d_setflag,
-                               pos0, nb, m_pass, pos0 + nb >= m ? 1 : 0, h->d_red + R::OFF_Q, c.d_scan);
+                               pos0, nb, m_pass, pos0 + nb >= m ? 1 : 0, h->d_red + R::OFF_Q, c.d_scan, c.d_forced);
         else
             hipLaunchKernelGGL(k_cov_gupdate, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, c.d_G, c.d_slot, h->p,
                                h->d_idx, h->d_hs, pos0, nb);
@@ -618,6 +620,8 @@ int32_t gc_fetch_entering(cdh_handle h, std::vector<int64_t>& enter, Cert&& cert
 // test_covariance_chunks_roll_back...) restores g and beta from the scan's snapshot and leaves the pass to the
 // windowed walk below, which knows how to stop at the offending position.
 enum { kDevDone = 0, kDevPlain = 1, kDevWalk = 2 };
+double g_dbg_book_us = 0, g_dbg_scan_us = 0, g_dbg_blocks_us = 0;
+constexpr int kGcForcedRounds = 4;     // a device pass whose re-check failed is run again this often with the failing coordinates visited
 template <typename Cert, typename Ratio>
 int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, double cert_abs, Cert&& cert, Ratio&& ratio,
                        int* outcome) {
@@ -634,7 +638,16 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
         HIPCHK(h, hipMemcpyAsync(c.d_pass_idx, h->h_idx, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
         c.pass_idx_host.assign(idx0, idx0 + m);
     }
+    // (the marks of a pass that was run again are wiped however the pass ends)
+    struct ForcedGuard {
+        cdh_handle h;
+        ~ForcedGuard() {
+            GradCache& c = h->gc;
+            if (c.forced_dirty) { (void)hipMemsetAsync(c.d_forced, 0, (size_t)h->p, h->stream); c.forced_dirty = false; }
+        }
+    } forced_guard{h};
     int cnt = 0;
+  for (int round = 0;; ++round) {
     for (int attempt = 0;; ++attempt) {
         h->ctrl.maxH = 0.0;
         h->ctrl.domain_error = 0;
@@ -642,10 +655,12 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
         h->ctrl.cert_abs = cert_abs;
         CHK(upload_ctrl(h));
         hipLaunchKernelGGL(k_cov_scan, dim3(1), dim3(1024), 0, h->stream, c.d_g, c.d_a, h->beta, h->omega, h->d_ctrl, c.d_pass_idx, (int)m,
-                           h->p, c.d_pos_of, c.d_setflag, c.d_upos, h->d_idx, c.d_g_snap, c.d_beta_snap, c.d_scan);
+                           h->p, c.d_pos_of, c.d_setflag, c.d_upos, h->d_idx, c.d_g_snap, c.d_beta_snap, c.d_scan, c.d_forced);
         HIPCHK(h, hipGetLastError());
+        const auto dbg_s0 = std::chrono::steady_clock::now();
         HIPCHK(h, hipMemcpyAsync(c.h_scanbuf, c.d_scanbuf, sizeof(int32_t) * (size_t)(m + 4), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        g_dbg_scan_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_s0).count();
         cnt = c.h_scan->count;
         if (c.h_scan->nzero > 0) return CDH_OK;     // a settled coordinate with g == 0 exactly: its bookkeeping differs; the walk knows
         std::vector<int64_t> enter;
@@ -668,9 +683,11 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
     c.backoff = 1;
     if (cnt > 0) {
         h->chunk_dup = false;
+        const auto dbg_k0 = std::chrono::steady_clock::now();
         CHK(launch_cov_blocks(h, cnt, true, (int)m));
         HIPCHK(h, hipGetLastError());
         CHK(cov_fetch_results(h, cnt, true));
+        g_dbg_blocks_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_k0).count();
         // (tests: CDH_GC_INJECT_ROLLBACK=N declares every N-th device pass failed after the fact, so that the undo and the
         // windowed walk that takes over are exercised on every problem of the suite, not only where a certificate breaks)
         const bool injected = c.inject_rollback > 0 && (++c.inject_count % c.inject_rollback) == 0;
@@ -680,6 +697,10 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipStreamSynchronize(h->stream));
             c.g_host_ok = host_ok_before;           // d_g is the gradient of the pass's start again
+            // coordinates that crossed their threshold through the pass's own moves (the first full pass after lambda has changed,
+            // on large supports: benchmark/cd_bench.jl's shape has them in most full passes beyond ~200 non-zeros): the same pass
+            // again with those on the visit list -- a device pass, not the windowed walk
+            if (!injected && round < kGcForcedRounds) { c.forced_dirty = true; c.n_forced_rounds += 1; continue; }
             c.n_rollbacks += 1;
             return CDH_OK;                          // -> the windowed walk
         }
@@ -687,7 +708,10 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
     } else {
         *h->h_ctrl = h->ctrl;                       // nothing ran: maxH 0, no domain error, r'r as it was
     }
+    break;
+  }
     // bookkeeping in visit order: what the reference's SparseIterate would have seen
+    const auto dbg_b0 = std::chrono::steady_clock::now();
     int j = 0;
     for (int64_t q = 0; q < m; ++q) {
         const int64_t k = idx0[q];
@@ -699,6 +723,7 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
     }
     c.n_exact += cnt; c.n_certified += m - cnt; c.n_dev_passes += 1;
     cov_accept_tail(h, cnt, maxH, false);
+    g_dbg_book_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_b0).count();
     *outcome = kDevDone;
     return CDH_OK;
 }

@@ -892,7 +892,7 @@ __global__ __launch_bounds__(1024) void k_cov_scan(const double* __restrict__ g,
                                                    int32_t* __restrict__ pos_of, uint8_t* __restrict__ setflag,
                                                    int32_t* __restrict__ upos, int64_t* __restrict__ vis,
                                                    double* __restrict__ g_snap, double* __restrict__ beta_snap,
-                                                   CovScanOut* out) {
+                                                   CovScanOut* out, const uint8_t* __restrict__ forced /* visited whatever their certificate says */) {
     __shared__ int s_wcnt[16];
     __shared__ int s_base, s_nzero;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(1024) void k_cov_scan(const double* __restrict__ g,
         const bool valid = i < m;
         const int64_t k = valid ? idx[i] : 0;
         const double gk = g[k];
-        const bool st = valid && cov_settled(gk, a[k], beta[k], thr_base, has_omega ? omega[k] : 1.0, cert_abs);
+        const bool st = valid && forced[k] == 0 && cov_settled(gk, a[k], beta[k], thr_base, has_omega ? omega[k] : 1.0, cert_abs);
         const bool uns = valid && !st;
         if (valid) { pos_of[k] = i; setflag[k] = st ? 1 : 0; }
         if (st && gk == 0.0) atomicAdd(&s_nzero, 1);
@@ -937,7 +937,10 @@ __global__ __launch_bounds__(256) void k_cov_restore(double* __restrict__ g, dou
 // pos_of[k], before those after it (sqrt-lasso: with ||r|| as it stands then, qs[] = r'r after each visit).  The block
 // answers for the skipped positions in (position of the previous block's last visit, position of its own last visit],
 // the last block of the pass also for those after its last visit.  A certificate that no longer holds is reported as
-// the smallest such position (out->bad_pos); the host then undoes the pass and walks it the careful way.
+// the smallest such position (out->bad_pos) and its coordinate marked in forced[]: the host undoes the pass and runs it
+// again with the marked coordinates on the visit list (visiting more than necessary is always right; everything from the
+// first broken position on was computed on a wrong trajectory, so later marks may be spurious: harmless), and only after
+// a few such rounds walks it the careful way.
 __global__ __launch_bounds__(256) void k_cov_gupdate_chk(double* __restrict__ g, const double* __restrict__ Gcols,
                                                          const int32_t* __restrict__ slot, const double* __restrict__ a,
                                                          const double* __restrict__ omega, const Ctrl* ctrl, int64_t p,
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(256) void k_cov_gupdate_chk(double* __restrict__ g,
                                                          const double* __restrict__ qs, const int32_t* __restrict__ upos,
                                                          const int32_t* __restrict__ pos_of, const uint8_t* __restrict__ setflag,
                                                          int j0, int nb, int m, int last_block, const double* __restrict__ q_start,
-                                                         CovScanOut* out) {
+                                                         CovScanOut* out, uint8_t* __restrict__ forced) {
     __shared__ double s_h[64], s_q[64];
     __shared__ int64_t s_off[64];
     __shared__ int s_pos[64];
@@ -983,13 +986,13 @@ __global__ __launch_bounds__(256) void k_cov_gupdate_chk(double* __restrict__ g,
     auto holds = [&](double gv, double qv) { return fabs(gv) <= cert_scale * (loss == 1 ? sqrt(qv) : n_total) - cert_off; };
     for (int i = 0; i < nmove; ++i) {
         if (need && s_pos[i] > t) {
-            if (!holds(acc, q_run)) atomicMin(&out->bad_pos, t);
+            if (!holds(acc, q_run)) { atomicMin(&out->bad_pos, t); forced[k] = 1; }
             need = false;
         }
         acc = fma(-s_h[i], Gcols[s_off[i] + k], acc);
         q_run = s_q[i];
     }
-    if (need && !holds(acc, q_run)) atomicMin(&out->bad_pos, t);
+    if (need && !holds(acc, q_run)) { atomicMin(&out->bad_pos, t); forced[k] = 1; }
     if (nmove) g[k] = acc;
 }
 

@@ -170,3 +170,82 @@ def test_sqrt_lasso_near_noiseless_keeps_its_residual_norm(loop):
         assert sorted(x.nzval2ind.tolist()) == sorted(xo.nzval2ind.tolist())
     assert f.cache_stats()["covariance_visits"] > 0
     f.close()
+
+
+@pytest.mark.parametrize("kind,rand", [("ls", False), ("ls", True), ("sqrt", False), ("wl1", True)],
+                         ids=["ls-ordered", "ls-random", "sqrt-ordered", "wl1-random"])
+def test_device_loop_table_mode_on_large_supports(kind, rand):
+    """Visit lists beyond the LDS-sized Gram block (~150 non-zeros; benchmark/cd_bench.jl's path ends at 774): the loop
+    reads X_j'X_k from its Gram table in device memory and carries the exact gradient of every coordinate the table holds.
+    A warm-started path whose support grows from ~100 to ~500 non-zeros (and shrinks again at the end: the last lambda is
+    larger), every lambda against the oracle with the same passes, visits and support order; then the loop off."""
+    rng, X, Y = _problem(97, 1600, 1400, 300, noise=2.0)
+    om = (rng.random(1400) + 0.5) if kind == "wl1" else None
+    if kind == "sqrt":
+        lams = list(np.exp(np.linspace(np.log(3.2), np.log(1.6), 14))) + [2.4]
+    else:
+        lams = list(np.exp(np.linspace(np.log(0.5), np.log(0.1), 14))) + [0.3]
+    o = dict(maxIter=5000, optTol=1e-9, randomize=rand, seed=41)
+    fo = O.CDSqrtLassoLoss(Y, X) if kind == "sqrt" else O.CDLeastSquaresLoss(Y, X)
+    xo, want = O.SparseIterate(1400), []
+    for lam in lams:
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam, om), O.CDOptions(**o))
+        assert st["converged"]
+        want.append((xo.dense().copy(), xo.nzval2ind.tolist(), st["passes"], st["visits"]))
+    sizes = [len(w[1]) for w in want]
+    assert max(sizes) > 300 and min(sizes) < 250, sizes
+    got = {}
+    for loop in (True, False):
+        f = cd.CDSqrtLassoLoss(Y, X) if kind == "sqrt" else cd.CDLeastSquaresLoss(Y, X)
+        f.set_gradient_cache(3)
+        f.set_onchip_solve(False)
+        f.set_device_loop(loop)
+        x, rec = cd.SparseIterate(1400), []
+        for lam, (beta, sup, passes, visits) in zip(lams, want):
+            cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(**o))
+            np.testing.assert_allclose(x.dense(), beta, rtol=0, atol=BETA_TOL)
+            assert x.nzval2ind.tolist() == sup, (loop, lam)
+            assert (f.last_stats["passes"], f.last_stats["visits"]) == (passes, visits), (loop, lam)
+            rec.append(x.dense().copy())
+        np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-8)
+        ls = f.device_loop_stats()
+        if loop:
+            assert ls["table"]["passes"] > 30 and ls["table"]["rows_filled"] > 200, ls
+            assert ls["table"]["coordinates"] <= ls["table"]["capacity"]
+        else:
+            assert ls["launches"] == 0 and ls["table"]["passes"] == 0
+        got[loop] = rec
+        f.close()
+    for a, b_ in zip(got[True], got[False]):
+        np.testing.assert_allclose(a, b_, rtol=0, atol=1e-11)
+
+
+def test_device_loop_table_survives_a_new_X_and_an_overflow(monkeypatch):
+    """The table holds X_j'X_k: set_X_cols voids it (the loop fills it afresh); a table that runs full starts over with
+    the current visit list.  Same answers as the oracle throughout."""
+    rng, X, Y = _problem(101, 1500, 2600, 200, noise=1.5)
+    o = dict(maxIter=5000, optTol=1e-9, randomize=False)
+    f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+    f.set_gradient_cache(3)
+    f.set_onchip_solve(False)
+    x, xo = cd.SparseIterate(2600), O.SparseIterate(2600)
+    for lam in np.exp(np.linspace(np.log(0.4), np.log(0.15), 10)):
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+        O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+    t0 = f.device_loop_stats()["table"]
+    assert t0["passes"] > 0 and t0["coordinates"] >= x.nnz > 160, (t0, x.nnz)
+    # new columns under the same handle: the table must not serve stale products
+    X2 = np.asfortranarray(X.copy())
+    X2[:, :300] = rng.standard_normal((1500, 300))
+    blk = np.asfortranarray(X2[:, :300])
+    cd._lib.check(f._L.cdh_set_X_cols(f._h, 0, 300, blk.ctypes.data, 1500), f._h)
+    fo2 = O.CDLeastSquaresLoss(Y, X2)
+    x, xo = cd.SparseIterate(2600), O.SparseIterate(2600)
+    for lam in np.exp(np.linspace(np.log(0.4), np.log(0.2), 8)):
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+        st = O.coordinateDescent_(xo, fo2, O.ProxL1(lam), O.CDOptions(**o))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"], lam
+    assert f.device_loop_stats()["table"]["passes"] > t0["passes"]
+    f.close()
