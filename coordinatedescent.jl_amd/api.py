@@ -330,9 +330,14 @@ class _HipLoss(CoordinateDifferentiableFunction):
         check(self._L.cdh_cache_gram_column(self._h, int(k), _vp(out), C.byref(eps)), self._h)
         return out, eps.value
 
-    def set_device_loop(self, on=True):
-        """The pass loop of a cache-served solve on the device (cdh_set_device_loop; on by default)."""
-        check(self._L.cdh_set_device_loop(self._h, int(bool(on))), self._h)
+    def set_device_loop(self, on=True, helpers=None):
+        """The pass loop of a cache-served solve on the device (cdh_set_device_loop; on by default).  helpers: 0 keeps the
+        loop to one workgroup (large visit lists then run from its Gram table only), n > 2 sets the number of helper
+        workgroups a launch that expects large visit lists brings (default 31)."""
+        v = int(bool(on))
+        if on and helpers is not None:
+            v = 2 if int(helpers) == 0 else max(3, int(helpers))
+        check(self._L.cdh_set_device_loop(self._h, v), self._h)
 
     def device_loop_stats(self):
         out = (C.c_int64 * 12)()
@@ -340,10 +345,11 @@ class _HipLoss(CoordinateDifferentiableFunction):
         d = dict(zip(("launches", "passes", "folds", "exact_rechecks"), [int(x) for x in out[:4]]))
         d["phase_us"] = dict(zip(("list", "scan", "exact_g", "visits", "recheck", "accept", "bookkeeping", "dropzeros_rest"),
                                  [int(x) / 100.0 for x in out[4:]]))
-        t = (C.c_int64 * 6)()
+        t = (C.c_int64 * 8)()
         check(self._L.cdh_device_loop_table(self._h, t), self._h)
         d["table"] = dict(zip(("passes", "rows_filled", "coordinates", "capacity"), [int(x) for x in t[:4]]))
         d["forced_rounds"] = {"host_pass": int(t[4]), "loop": int(t[5])}
+        d["crew"] = {"passes": int(t[6]), "jobs": int(t[7])}
         return d
 
     def set_use_graph(self, on=True):

@@ -13,7 +13,6 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include <chrono>
 
 #include "kernels.hpp"
 #include "gram_kernels.hpp"
@@ -115,7 +114,7 @@ struct GradCache {
     int32_t *d_pos_of = nullptr, *d_upos = nullptr;
     uint8_t *d_setflag = nullptr, *d_forced = nullptr;   // (d_forced: the second half of d_setflag's allocation)
     bool forced_dirty = false;
-    int64_t n_forced_rounds = 0, n_cs_forced_rounds = 0;
+    int64_t n_forced_rounds = 0, n_cs_forced_rounds = 0, n_cs_crew_passes = 0, n_cs_crew_jobs = 0;
     // the scan's counters sit at the head of the buffer of unsettled positions (one copy brings both back); the results of
     // a pass come back through k_cov_pack's block
     int32_t *d_scanbuf = nullptr, *h_scanbuf = nullptr;   // [CovScanOut: 4 int32][positions: cap]; h_: pinned
@@ -142,6 +141,7 @@ struct GradCache {
             n_reconcile = 0;
     // the device-resident pass loop (cov_solve.hpp): its scratch, the pinned block it reads from and writes into, the bound's M_k
     bool cs_enabled = true;          // env CDH_COV_SOLVE (default 1)
+    int cs_helpers = 31;             // helper workgroups a launch that expects large visit lists brings (env CDH_CS_CREW; 0: none, table mode only)
     bool cs_shuffle_ok = true, cs_stalled = false;
     size_t cs_lds_budget = 0;
     char *cs_dev = nullptr, *cs_pin = nullptr, *cs_pin_dev = nullptr;
@@ -157,7 +157,7 @@ struct GradCache {
     int64_t n_cs_launches = 0, n_cs_passes = 0, n_cs_folds = 0, n_cs_exact = 0, n_cs_table_passes = 0, n_cs_table_rows = 0;
     int32_t cs_ncid = 0, cs_tepoch = 0;      // the kernel's Gram table: coordinates it holds, the epoch of its carried gradients
     bool cs_table_reset = true;
-    int64_t cs_ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs_cycles = 0, cs_ticks_total = 0, cs_dbg[4] = {0, 0, 0, 0};
+    int64_t cs_ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs_cycles = 0, cs_ticks_total = 0;
 };
 
 // The one-launch solve of problems that fit on chip (small_solve.hpp): the full Gram matrix of the resident X, the
@@ -1083,7 +1083,6 @@ int32_t run_pass(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, boo
 }
 
 // _coordinateDescent! (coordinate_descent.jl:65-92)
-double g_dbg_pass_us[2] = {0, 0}; long g_dbg_pass_n[2] = {0, 0};
 int32_t solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched, cdh_stats* st) {
     bool prev_converged = false, converged = true;
     std::vector<int64_t> visit;
@@ -1100,10 +1099,8 @@ int32_t solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched, cd
         const bool full = converged;
         sched.next_pass(h->x, full, visit);
         double maxH = 0.0;
-        const auto dbg_t0 = std::chrono::steady_clock::now();
         if (!visit.empty()) CHK(run_pass(h, visit.data(), (int64_t)visit.size(), &maxH, full));
         else h->x.dropzeros();
-        { const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count(); g_dbg_pass_us[full ? 0 : 1] += us; g_dbg_pass_n[full ? 0 : 1] += 1; }
         h->gc.prep_state = 0;
         st->passes += 1; st->visits += (int64_t)visit.size(); st->maxH = maxH;
         if (full) st->full_passes += 1;
@@ -1244,6 +1241,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->gc.mode = std::max(0, std::min(3, env_int("CDH_GRADIENT_CACHE", 1)));
         h->gc.cov = env_int("CDH_GC_COV", 1) != 0;
         h->gc.cs_enabled = env_int("CDH_COV_SOLVE", 1) != 0;
+        h->gc.cs_helpers = std::max(0, std::min(kCsCrewMax, env_int("CDH_CS_CREW", 31)));
         h->small.enabled = env_int("CDH_SMALL_PATH", 1) != 0;
         if (const char* e = getenv("CDH_SMALL_MAX_BYTES")) h->small.max_bytes = std::atoll(e);
         h->small.zero_copy = env_int("CDH_SMALL_ZEROCOPY", 1) != 0;
@@ -1994,6 +1992,8 @@ int32_t cdh_cache_gram_column(cdh_handle h, int64_t k1, double* out_p, double* o
 int32_t cdh_set_device_loop(cdh_handle h, int32_t on) {
     NEED_H(h);
     h->gc.cs_enabled = on != 0;
+    if (on == 2) h->gc.cs_helpers = 0;                 // the loop without its helper workgroups
+    else if (on > 2) h->gc.cs_helpers = std::min(kCsCrewMax, on);
     return CDH_OK;
 }
 
@@ -2002,18 +2002,15 @@ int32_t cdh_device_loop_stats(cdh_handle h, int64_t* out12) {
     NEED_P(h, out12);
     out12[0] = h->gc.n_cs_launches; out12[1] = h->gc.n_cs_passes; out12[2] = h->gc.n_cs_folds; out12[3] = h->gc.n_cs_exact;
     for (int i = 0; i < 8; ++i) out12[4 + i] = h->gc.cs_ticks[i];
-    if (getenv("CDH_PASS_TIMES")) fprintf(stderr, "visits phase: staging %.0f us, visits %.0f us, after-visit %.0f us, gradient update %.0f us\n", h->gc.cs_dbg[0] / 100.0, h->gc.cs_dbg[1] / 100.0, h->gc.cs_dbg[2] / 100.0, h->gc.cs_dbg[3] / 100.0);
-    if (getenv("CDH_PASS_TIMES")) fprintf(stderr, "host device passes: scan+sync %.0f us, blocks+fetch %.0f us, bookkeeping %.0f us\n", g_dbg_scan_us, g_dbg_blocks_us, g_dbg_book_us);
-    if (getenv("CDH_PASS_TIMES")) fprintf(stderr, "host passes: full %ld in %.0f us, active %ld in %.0f us\n", g_dbg_pass_n[0], g_dbg_pass_us[0], g_dbg_pass_n[1], g_dbg_pass_us[1]);
     if (getenv("CDH_COV_SOLVE_CLOCK")) fprintf(stderr, "k_cov_solve: %lld cycles in %lld ticks of 10 ns: %.3f GHz\n", (long long)h->gc.cs_cycles, (long long)h->gc.cs_ticks_total, h->gc.cs_ticks_total ? (double)h->gc.cs_cycles / (double)h->gc.cs_ticks_total * 0.1 : 0.0);
     return CDH_OK;
 }
 
-int32_t cdh_device_loop_table(cdh_handle h, int64_t* out6) {
+int32_t cdh_device_loop_table(cdh_handle h, int64_t* out6 /* eight values by now */) {
     NEED_H(h);
     NEED_P(h, out6);
     out6[0] = h->gc.n_cs_table_passes; out6[1] = h->gc.n_cs_table_rows; out6[2] = h->gc.cs_table_reset ? 0 : h->gc.cs_ncid; out6[3] = kCsTableCap;
-    out6[4] = h->gc.n_forced_rounds; out6[5] = h->gc.n_cs_forced_rounds;
+    out6[4] = h->gc.n_forced_rounds; out6[5] = h->gc.n_cs_forced_rounds; out6[6] = h->gc.n_cs_crew_passes; out6[7] = h->gc.n_cs_crew_jobs;
     return CDH_OK;
 }
 

@@ -50,7 +50,7 @@ constexpr size_t kCsLdsBudget = (size_t)134 * 1024;   // dynamic LDS next to ~24
 constexpr int kCsTrackedMargin = 24;     // room in the tracked list for entering and near-threshold coordinates next to the support
 constexpr int kCsTableCap = 1536;        // coordinates the Gram table of large visit lists holds (1536^2 doubles = 18.9 MB of device memory)
 constexpr int kCsTableMargin = 160;      // ... of which this many are left to entering and near-threshold coordinates next to the support
-constexpr size_t kCsTableLds = 2688 + 64 * 64;    // doubles of dynamic LDS table mode uses (a GramRec<4> record rounded up, a tile)
+constexpr size_t kCsTableLds = 2688 + 64 * 64 + 640;    // doubles of dynamic LDS table mode and crew passes use (a GramRec<4> record rounded up, a tile, a block's moves)
 constexpr int kCsForcedRounds = 4;       // a full pass whose re-check found coordinates crossing their threshold is run again this often with those visited
 constexpr int kCsUcapMax = 176;          // tracked coordinates whose Gram block is kept in LDS: symmetric, upper triangle packed (176 x 177 / 2 doubles = 122 KB)
 __host__ __device__ constexpr size_t cs_tri_doubles(size_t u) { return u * (u + 1) / 2; }
@@ -117,6 +117,121 @@ __device__ __forceinline__ int cs_block_sum(int v, int* s_w) {
     return tot;
 }
 
+
+// ---- the crew ----------------------------------------------------------------------------------------------------------
+// Beyond the LDS-sized Gram block the work per block of 64 visits that is NOT the visits themselves -- g -= sum_i h_i G_i over
+// all p coordinates, and in a full pass the re-check of every skipped coordinate at its turn (k_cov_gupdate_chk's job in the
+// host's device pass) -- is p x 64 gathers: microseconds for thirty workgroups, ~1 ms for one.  So a launch that expects such
+// lists brings helpers: workgroups 1 .. of the same grid.  Workgroup 0 runs the state machine as before and POSTS one job per
+// block (the block's moves: h, column offsets, visit indices, r'r after each); the helpers take the jobs in order, each for
+// its slice of the coordinates, and report per helper how many they have finished.  Workgroup 0 never waits for the job it has
+// just posted: the 64 gradients the next block needs it brings up to date itself (a 64 x 64 tile of Gram entries, the same
+// sums in the same order) and tells the helpers to leave those coordinates alone for that job (hold[k] = the job's tag).
+// Memory model: job data and g are ordinary device memory; a post is release (agent scope) after the data, a take is acquire;
+// a helper's report is release after its stores, workgroup 0's wait acquire.  Every spin is bounded by the wall clock (100 MHz
+// counter): a helper that hears nothing for kCsCrewPatience leaves, workgroup 0 gives up a wait after the same time and the
+// solve fails loudly (kCsCrewLost) -- a hang is not possible; all helpers are resident (one workgroup per CU, far fewer than CUs).
+constexpr uint64_t kCsCrewPatience = 2000000000ull;      // 20 s of 10 ns ticks
+
+__device__ __forceinline__ uint32_t cs_ld_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t cs_ld_relaxed(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cs_st_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct CsCrewView {      // what a helper touches (passed by value: a handful of registers)
+    CsCrew* crew; int64_t p; double* g; double* g_snap; const double* Gcols; const uint32_t* hold; const int32_t* vb;
+    const uint8_t* setflag; const double* omega; const double* a; uint8_t* forced; const double* pendv; const int64_t* poff;
+};
+__device__ __attribute__((noinline)) void cs_crew_helper(const CovSolveCtl* ctl, const CsCrewView b) {
+    __shared__ double s_h[64], s_q[64];
+    __shared__ int64_t s_off[64];
+    __shared__ int s_pos[64];
+    __shared__ int s_go;
+    const int tid = threadIdx.x, hid = (int)blockIdx.x - 1, nh = (int)gridDim.x - 1;
+    CsCrew* cw = b.crew;
+    const int64_t p = b.p;
+    const int loss = ctl->loss, has_omega = ctl->has_omega;
+    const double lambda0 = ctl->lambda0, n_total = ctl->n_total, cert_abs = ctl->cert_abs;
+    uint32_t seen = 0;
+    for (;;) {
+        if (tid == 0) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            int go = 1;
+            for (;;) {       // (polled relaxed, a few times per microsecond: the acquire is the fence below)
+                if (cs_ld_relaxed(&cw->posted) > seen) break;
+                if (cs_ld_relaxed(&cw->exit_flag) != 0) { if (cs_ld_relaxed(&cw->posted) > seen) break; go = 0; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > kCsCrewPatience) { go = 0; break; }
+                __builtin_amdgcn_s_sleep(12);
+            }
+            s_go = go;
+        }
+        __syncthreads();
+        const int go = s_go;
+        if (!go) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const CsCrewJob* job = &cw->ring[seen & 1];
+        const int kind = job->kind;
+        if (kind == kCrewSnapshot) {
+            for (int64_t k = (int64_t)hid * kCsThreads + tid; k < p; k += (int64_t)nh * kCsThreads) b.g_snap[k] = b.g[k];
+        } else if (kind == kCrewRestore) {
+            for (int64_t k = (int64_t)hid * kCsThreads + tid; k < p; k += (int64_t)nh * kCsThreads) b.g[k] = b.g_snap[k];
+        } else if (kind == kCrewFold) {          // g -= sum_m pend_m G_m: the moves the table-mode passes have left pending, in their order
+            const int nm = job->nmove;
+            for (int64_t k = (int64_t)hid * kCsThreads + tid; k < p; k += (int64_t)nh * kCsThreads) {
+                double acc = b.g[k];
+                int m = 0;
+                for (; m + 16 <= nm; m += 16) {
+                    double gv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gv[r] = b.Gcols[b.poff[m + r] + k];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc = fma(-b.pendv[m + r], gv[r], acc);
+                }
+                for (; m < nm; ++m) acc = fma(-b.pendv[m], b.Gcols[b.poff[m] + k], acc);
+                b.g[k] = acc;
+            }
+        } else {
+            const int nmove = job->nmove, j0 = job->j0, nb = job->nb, chk = job->chk, last_block = job->last_block;
+            const uint32_t tag = job->hold_tag;
+            const double q_start = job->q_start;
+            if (tid < 64) { s_h[tid] = job->h[tid]; s_q[tid] = job->q[tid]; s_off[tid] = job->off[tid]; s_pos[tid] = job->pos[tid]; }
+            __syncthreads();
+            for (int64_t k = (int64_t)hid * kCsThreads + tid; k < p; k += (int64_t)nh * kCsThreads) {
+                if (b.hold[k] == tag) continue;                   // workgroup 0 has brought this one up to date itself
+                const int t = b.vb[k];                            // (a skipped coordinate: the visits before its turn)
+                bool need = chk != 0 && b.setflag[k] != 0 && t >= j0 && (last_block != 0 || t < j0 + nb);
+                if (nmove == 0 && !need) continue;
+                double acc = b.g[k], q_run = q_start;
+                double cert_scale = 0.0, cert_off = 0.0;
+                if (need) { cert_scale = lambda0 * (has_omega ? b.omega[k] : 1.0) * (1.0 - 1e-9); cert_off = cert_abs * sqrt(b.a[k]); }
+                auto holds = [&](double gv, double qv) { return fabs(gv) <= cert_scale * (loss == 1 ? sqrt(qv) : n_total) - cert_off; };
+                for (int i0 = 0; i0 < nmove; i0 += 32) {
+                    double gv[32];
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) gv[r] = b.Gcols[s_off[min(i0 + r, nmove - 1)] + k];
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) {
+                        const int i = i0 + r;
+                        if (i < nmove) {
+                            if (need && s_pos[i] >= t) {
+                                if (!holds(acc, q_run)) { b.forced[k] = 1; cw->bad = 1; }
+                                need = false;
+                            }
+                            acc = fma(-s_h[i], gv[r], acc);
+                            q_run = s_q[i];
+                        }
+                    }
+                }
+                if (need && !holds(acc, q_run)) { b.forced[k] = 1; cw->bad = 1; }
+                if (nmove) b.g[k] = acc;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        seen += 1;
+        if (tid == 0) cs_st_release(&cw->done[hid], seen);
+    }
+}
+
 constexpr int kCsE = 4;      // positions per thread and iteration of the p-sized loops: their loads are issued together,
                              // so those loops are written WITHOUT short-circuit conditions (a conditional load is waited for on its own)
 
@@ -130,6 +245,7 @@ struct CsTracked {
 constexpr size_t kCsTrackedBytes = 3 * 8 + 7 * 8 + 4;      // per tracked coordinate
 
 __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovSolveBufs b, int ucap /* tracked coordinates whose Gram block fits LDS */) {
+    if (blockIdx.x != 0) { cs_crew_helper(ctl, CsCrewView{b.crew, b.p, b.g, b.g_snap, b.Gcols, b.hold, b.vb, b.setflag, b.omega, b.a, b.forced, b.pendv, b.poff}); return; }        // the crew (above): no barrier of workgroup 0 is theirs
     using R = GramRec<4>;
     constexpr int B = R::B;
     constexpr int E = kCsE;
@@ -154,15 +270,43 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     double q = ctl->q;
     const double q_floor = ctl->q_floor;
     // 100 MHz ticks per phase (thread 0's view): list, scan, exact gradients, visits, re-check, accept, bookkeeping, dropzeros!
-    uint64_t tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tdbg[4] = {0, 0, 0, 0}, tdm = 0;
-    auto dlap = [&](int ph) { const uint64_t now = __builtin_amdgcn_s_memrealtime(); tdbg[ph] += now - tdm; tdm = now; };
+    uint64_t tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tmark = __builtin_amdgcn_s_memrealtime();
     const uint64_t cyc0 = __builtin_amdgcn_s_memtime(), tick0 = tmark;
     auto lap = [&](int ph) { const uint64_t now = __builtin_amdgcn_s_memrealtime(); tph[ph] += now - tmark; tmark = now; };
     int nnz = ctl->nnz, inject_count = ctl->inject_count;
     const int tcap = ctl->tcap, fold_limit = ctl->fold_limit, full_cap = ctl->full_cap;
     int ncid = ctl->ncid, tepoch = ctl->tepoch + 1;      // (gradients the table carried belong to the launch that carried them)
-    int64_t table_passes = 0, table_rows = 0, forced_rounds = 0;
+    int64_t table_passes = 0, table_rows = 0, forced_rounds = 0, crew_passes = 0, crew_jobs = 0;
+    const int nhelp = (int)gridDim.x - 1;
+    const bool crew = nhelp > 0;
+    CsCrew* cw = b.crew;
+    uint32_t njobs = 0, known_done = 0;
+    bool crew_lost = false;
+    __shared__ uint32_t s_known;
+    // every helper has finished `target` jobs (called by all threads; the spin is bounded by the wall clock)
+    auto crew_wait = [&](uint32_t target) {
+        if (target <= known_done) return;
+        if (tid < 64) {
+            uint32_t v = 0xffffffffu;
+            if (tid < nhelp) {
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    v = cs_ld_relaxed(&cw->done[tid]);
+                    if (v >= target || __builtin_amdgcn_s_memrealtime() - t0 > kCsCrewPatience) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o < v ? o : v; }
+            if (tid == 0) s_known = v;
+        }
+        __syncthreads();
+        known_done = s_known;
+        if (known_done < target) crew_lost = true;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+    };
     int forced_rounds_here = 0;
     bool forced_dirty = false;
     bool prev_conv = ctl->prev_conv != 0, conv = ctl->conv != 0;
@@ -180,6 +324,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     const CsTracked gt{b.uk, b.voff, b.iota, b.ubeta, b.uom, b.ugx, b.hs, b.newval, b.qs, b.tv, b.touched};   // ... and the global one
 
     for (int64_t k = tid; k < p; k += kCsThreads) { b.i2s[k] = 0; b.bfold[k] = b.beta[k]; b.inmoved[k] = 0; b.gxp[k] = -1; b.iota[k] = k; }
+    if (crew) for (int64_t k = tid; k < p; k += kCsThreads) b.hold[k] = 0;
     for (int u = tid; u < ucap; u += kCsThreads) lt.iota[u] = u;
     if (tid == 0) {
         s_nfail = 0;
@@ -249,13 +394,49 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         if (cov_visits > cov_budget) { status = kCsRefresh; break; }
         if (sqrt_loss && q < q_floor) { status = kCsNeedQ; break; }      // r'r has run out of digits: the host sums it from r
         const bool full = conv;
-        if (full && nnz > full_cap) { status = kCsHostFull; break; }
+        if (full && nnz > full_cap && !crew) { status = kCsHostFull; break; }
+        if (crew) {
+            crew_wait(njobs);                                       // g is as current as the jobs posted so far make it
+            if (full && nmoved > 0 && nnz + kCsTrackedMargin > ucap) {
+                // a full pass of a large support is a crew pass (below): the moves the table-mode passes have left pending are folded
+                // into g first -- p x moves gathers, the helpers' work
+                stage_pending();
+                if (tid < 64) {
+                    CsCrewJob* job = &cw->ring[njobs & 1];
+                    if (tid == 0) { job->kind = kCrewFold; job->nmove = nmoved; job->hold_tag = njobs + 1; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (tid == 0) cs_st_release(&cw->posted, njobs + 1);
+                }
+                njobs += 1; crew_jobs += 1;
+                for (int m = tid; m < nmoved; m += kCsThreads) { const int km = b.moved[m]; b.bfold[km] = b.beta[km]; b.inmoved[km] = 0; }
+                crew_wait(njobs);
+                nmoved = 0; TV0 = 0.0; folds += 1; pass_id += 2; tepoch += 1;
+            }
+            if (crew_lost) { status = kCsCrewLost; break; }
+        }
         const uint64_t rng_before = rng;
         const int L = full ? (int)p : nnz;
         const int Lm1 = L > 0 ? L - 1 : 0;
         const bool direct = full && !randomize;      // an ordered full pass visits k = i: no list
         // ---- reset!(it, full) + collect(it) (atom_iterator.jl:34-37, 53-64; the splitmix64 substitute of sparse_iterate.hpp) ----
-        if (randomize) {
+        if (randomize && L <= 64) {
+            // one lane per position: Fisher-Yates in the registers of wave 0 (small_solve.hpp's wave_build_list), no scratch
+            if (tid < 64) {
+                int dr = tid;
+                if (tid + 1 < L) {
+                    uint64_t st = rng + (uint64_t)tid * 0x9E3779B97F4A7C15ull;
+                    dr = tid + (int)mod64_small(small_rng_next(st), (uint32_t)(L - tid));
+                }
+                int val = tid;
+                for (int i = 0; i + 1 < L; ++i) {
+                    const int j = __builtin_amdgcn_readlane(dr, i);
+                    const int vi = __builtin_amdgcn_readlane(val, i), vj = __builtin_amdgcn_readlane(val, j);
+                    val = tid == i ? vj : (tid == j ? vi : val);
+                }
+                if (tid < L) b.list[tid] = full ? val : b.s2i[val];
+            }
+            if (L > 1) rng += (uint64_t)(L - 1) * 0x9E3779B97F4A7C15ull;
+        } else if (randomize) {
             // the shuffle's six (p + 1)-sized arrays overlay the tracked Gram block (and arrays) in LDS, which are refilled below anyway (a
             // shuffled pass visits its coordinates in a new order); Fisher-Yates itself without the serial swaps: small_solve.hpp
             int32_t* f_draw = reinterpret_cast<int32_t*>(s_dynamic);
@@ -356,8 +537,10 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         // kept current there, else g - sum_m pend_m G_m), their Gram block ----
         stage_pending();
         const bool in_lds = cnt <= ucap;
-        const bool table = !in_lds;      // a visit list beyond the LDS-sized Gram block: the Gram TABLE in device memory (see k_cov_solve's header)
+        const bool crewp = crew && !in_lds && full;      // a full pass over a visit list beyond the LDS-sized Gram block, helpers present: a crew pass
+        const bool table = !in_lds && !crewp;    // ... no helpers: the Gram TABLE in device memory (see k_cov_solve's header)
         if (table && cnt > tcap) { status = kCsOutgrown; rng = rng_before; break; }
+        if (crewp && nmoved > 0) { status = kCsNeedFold; rng = rng_before; break; }     // (the helpers keep g itself current: nothing may be pending on it)
         const CsTracked T = in_lds ? lt : gt;
         if (tid == 0) s_same = (in_lds && cnt == cnt_prev) ? 1 : 0;
         __syncthreads();
@@ -394,7 +577,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             if (table) {                 // the table carries the exact gradient of every coordinate it holds through all the moves of table-mode passes
                 const int c = b.ucid[u];
                 if (b.gxe[c] != tepoch) { b.gxc[c] = (gp == pass_id - 1) ? gxk : exact_g(k); b.gxe[c] = tepoch; }
-            } else {
+            } else if (!crewp) {
                 T.gx[u] = (gp == pass_id - 1) ? gxk : exact_g(k);
             }
             if (kprev != k) s_same = 0;
@@ -450,7 +633,6 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         // (on the tracked arrays: `beta` and `omega` indexed by position, the identity as the block's coordinate list) ----
         if (in_lds) for (int j0 = 0; j0 < cnt; j0 += B) {
             const int nb = min(B, cnt - j0);
-            tdm = __builtin_amdgcn_s_memrealtime();
             for (int e = tid; e < B * B; e += kCsThreads) {
                 const int sI = e / B, j = e % B;
                 if (sI <= j && j < nb) s_rec[R::g(sI, j)] = s_G[cs_tri(j0 + sI, j0 + j, cnt)];
@@ -458,10 +640,8 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             if (tid < B) s_rec[R::OFF_C + tid] = (tid < nb) ? T.gx[j0 + tid] : 0.0;
             if (tid == 0) s_rec[R::OFF_Q] = s_ctrl.q_carry;
             __syncthreads();
-            dlap(0);
             if (tid < 64) {
                 gram_scalar_body<4>(s_rec, nb, 0, &s_ctrl, T.beta, T.om, T.iota, T.hs, T.nv, T.tch, j0, T.qs, tid);
-                dlap(1);
                 // the block's moves, compacted (k_cov_gupdate's prologue), and the total variation after each visit
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -480,7 +660,6 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 if (tid == 0) s_tvrun = base + last;
             }
             __syncthreads();
-            dlap(2);
             const int nmove = s_nmove;
             if (nmove > 0)               // every tracked coordinate sees the block's moves (the block's own members too: gx stays current)
                 for (int u = tid; u < cnt; u += kCsThreads) {
@@ -489,33 +668,53 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     T.gx[u] = acc;
                 }
             __syncthreads();
-            dlap(3);
         }
-        if (table && cnt > 0) {
-            // Table mode, two blocks in flight.  The update of the table's gradients with a block's moves (64 rows of Gc, ~400 KB at 800
-            // coordinates: the L1 of one CU moves that in ~4 us, as long as the block's 64 visits take) runs on waves 1-3 WHILE wave 0 visits
-            // the next block; that block's own 64 gradients get the moves first (a 64 x 64 tile of Gc, summed in the same order: bit for bit
-            // what the rows will leave in gxc), and its Gram block was gathered during the block before.  Per block: tile + visits instead
-            // of gather + visits + rows (13.6 -> ~8 us at benchmark/cd_bench.jl's shape).
+        if ((table || crewp) && cnt > 0) {
+            // Visit lists beyond the LDS block, two blocks in flight.
+            // Table mode (active passes; full passes of a launch without helpers never get here): the update of the table's gradients
+            // with a block's moves (64 rows of Gc, ~400 KB at 800 coordinates: the L1 of one CU moves that in ~4 us, as long as the block's
+            // 64 visits take) runs on waves 1-3 WHILE wave 0 visits the next block; that block's own 64 gradients get the moves first (a
+            // 64 x 64 tile of Gc, summed in the same order: bit for bit what the rows will leave in gxc), and its Gram block was gathered
+            // during the block before.
+            // A crew pass (full passes of a launch with helpers): g[k] itself is the gradient of every coordinate (nothing pending, no
+            // bound).  Same pipeline, the Gram entries straight from the cached columns; the tile's result is written back to g and the
+            // helpers are told to leave those 64 coordinates alone for the job of the block before; after its visits workgroup 0 POSTS the
+            // block's moves: the helpers apply them to all other coordinates and re-check every skipped coordinate at its turn (marks in
+            // forced[], cw->bad) -- one job behind, never waited for inside the pass.
             const int nch = (cnt + B - 1) / B;
             auto recb = [&](int which) -> double* { return which ? s_dynamic : s_rec; };
             static_assert(R::N <= 2688, "the second block record");
-            double* s_tile = s_dynamic + 2688;                   // [64 moves][64 ids] of the block about to be visited
+            double* s_tile = s_dynamic + 2688;                                       // [64 moves][64 coordinates] of the block about to be visited
+            int64_t* s_off2 = reinterpret_cast<int64_t*>(s_dynamic + 6784);           // crew: [2][B] column offsets of a block's moves
+            int64_t* s_k2 = s_off2 + 2 * B;                                          //       [2][B] coordinates of a block
+            double* s_q2 = reinterpret_cast<double*>(s_k2 + 2 * B);                  //       [2][B] r'r after each move
+            int* s_pos2 = reinterpret_cast<int*>(s_q2 + 2 * B);                      //       [2][B] visit index of each move
+            int64_t* s_v2 = reinterpret_cast<int64_t*>(s_pos2 + 2 * B);              //       [2][B] column offsets of a block's coordinates
             const int lane_t = tid & 63, part = tid >> 6;
-            double gv[B * B / kCsThreads];
-            auto gather_block = [&](int jb) {                    // Gc[id_j][id_sI] of block jb for this thread's 16 (sI, j) pairs: all in flight
-                const int cj = b.ucid[min(jb + lane_t, cnt - 1)];
-                int ci[B * B / kCsThreads];
+            // (the next block's Gram entries are fetched by waves 1-3 only: loads return in order, and wave 0's visits start with loads of their own)
+            constexpr int NGV = (B * B + (kCsThreads - 64) - 1) / (kCsThreads - 64);
+            double gv[NGV];
+            auto stage_ids = [&](int which, int jb) {            // the coordinates (crew) / table ids of block jb into LDS, by one wave's lanes
+                if (crewp) { s_k2[which * B + lane_t] = T.k[min(jb + lane_t, cnt - 1)]; s_v2[which * B + lane_t] = T.voff[min(jb + lane_t, cnt - 1)]; }
+                else s_cid2[which][lane_t] = b.ucid[min(jb + lane_t, cnt - 1)];
+            };
+            auto gather_block = [&](int which) {
+                if (tid < 64) return;
 #pragma unroll
-                for (int t = 0; t < B * B / kCsThreads; ++t) ci[t] = b.ucid[min(jb + part + 4 * t, cnt - 1)];
-#pragma unroll
-                for (int t = 0; t < B * B / kCsThreads; ++t) gv[t] = b.Gc[(size_t)cj * tcap + ci[t]];
+                for (int t = 0; t < NGV; ++t) {
+                    const int e = min(tid - 64 + (kCsThreads - 64) * t, B * B - 1), j = e & (B - 1), sI = e / B;
+                    gv[t] = crewp ? b.Gcols[s_v2[which * B + j] + s_k2[which * B + sI]] : b.Gc[(size_t)s_cid2[which][j] * tcap + s_cid2[which][sI]];
+                }
             };
             auto store_block = [&](double* rec, int nbn) {
+                if (tid < 64) return;
 #pragma unroll
-                for (int t = 0; t < B * B / kCsThreads; ++t) { const int sI = part + 4 * t; if (sI <= lane_t && lane_t < nbn) rec[R::g(sI, lane_t)] = gv[t]; }
+                for (int t = 0; t < NGV; ++t) {
+                    const int e = tid - 64 + (kCsThreads - 64) * t, sI = e / B, j = e & (B - 1);
+                    if (e < B * B && sI <= j && j < nbn) rec[R::g(sI, j)] = gv[t];
+                }
             };
-            auto rows_update = [&](const double* hb, const int* mub, int nmv) {   // gxc -= sum_i h_i Gc[mu_i][.], moves in visit order
+            auto rows_update = [&](const double* hb, const int* mub, int nmv) {   // table mode: gxc -= sum_i h_i Gc[mu_i][.], moves in visit order
                 // 256 ids at a time per wave, handed out by a counter: the waves that only move memory start at once, wave 0 joins after its visits
                 for (;;) {
                     int task = 0;
@@ -526,22 +725,12 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     if (c0 >= ncid) continue;
                     double4 acc = *reinterpret_cast<const double4*>(b.gxc + c0);
                     int i = 0;
-                    for (; i + 16 <= nmv; i += 16) {
-                        double4 rv[16];
+                    for (; i + 8 <= nmv; i += 8) {
+                        double4 rv[8];
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) rv[t] = *reinterpret_cast<const double4*>(b.Gc + (size_t)mub[i + t] * tcap + c0);
+                        for (int t = 0; t < 8; ++t) rv[t] = *reinterpret_cast<const double4*>(b.Gc + (size_t)mub[i + t] * tcap + c0);
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) {
-                            const double hv = -hb[i + t];
-                            acc.x = fma(hv, rv[t].x, acc.x); acc.y = fma(hv, rv[t].y, acc.y); acc.z = fma(hv, rv[t].z, acc.z); acc.w = fma(hv, rv[t].w, acc.w);
-                        }
-                    }
-                    for (; i + 4 <= nmv; i += 4) {
-                        double4 rv[4];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) rv[t] = *reinterpret_cast<const double4*>(b.Gc + (size_t)mub[i + t] * tcap + c0);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
+                        for (int t = 0; t < 8; ++t) {
                             const double hv = -hb[i + t];
                             acc.x = fma(hv, rv[t].x, acc.x); acc.y = fma(hv, rv[t].y, acc.y); acc.z = fma(hv, rv[t].z, acc.z); acc.w = fma(hv, rv[t].w, acc.w);
                         }
@@ -554,48 +743,80 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     *reinterpret_cast<double4*>(b.gxc + c0) = acc;       // (ids beyond ncid up to the next multiple of four: scratch nobody reads)
                 }
             };
-            if (tid < B) s_cid2[0][tid] = b.ucid[min(tid, cnt - 1)];
+            // crew: one job; wave 0 writes it (the slot's previous job -- two posts ago -- is finished: every caller has waited for njobs - 1)
+            auto crew_post = [&](int kind, int par, int nmv, int j0, int nb, int chk, int last, int hold_j0, double q_start) {
+                if (tid < 64) {
+                    CsCrewJob* job = &cw->ring[njobs & 1];
+                    if (kind == kCrewUpdate) {
+                        job->h[tid] = tid < nmv ? s_h2[par][tid] : 0.0; job->q[tid] = s_q2[par * B + tid];
+                        job->off[tid] = s_off2[par * B + tid]; job->pos[tid] = s_pos2[par * B + tid];
+                        if (hold_j0 >= 0 && hold_j0 + tid < cnt) b.hold[T.k[hold_j0 + tid]] = njobs + 1;
+                    }
+                    if (tid == 0) {
+                        job->kind = kind; job->nmove = nmv; job->j0 = j0; job->nb = nb; job->chk = chk; job->last_block = last; job->cnt = cnt;
+                        job->hold_tag = njobs + 1; job->q_start = q_start;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (tid == 0) cs_st_release(&cw->posted, njobs + 1);
+                }
+                njobs += 1; crew_jobs += 1;
+            };
+            if (crewp) {
+                if (tid == 0) cw->bad = 0;                       // (every job is finished: nobody else touches it now)
+                crew_post(kCrewSnapshot, 0, 0, 0, 0, 0, 0, -1, 0.0);          // g as the pass finds it, should the pass have to be undone
+            }
+            if (part == 1) stage_ids(0, 0);
+            __syncthreads();
             gather_block(0);
             store_block(recb(0), min(B, cnt));
             __syncthreads();
-            int pend_n = 0;                                       // moves of the block before, not yet in gxc
+            int pend_n = 0;                                       // moves of the block before, not yet in gxc / in this block's gradients
             for (int ch = 0; ch < nch; ++ch) {
                 const int par = ch & 1, j0 = ch * B, nb = min(B, cnt - j0);
                 double* rec = recb(par);
-                const int* cid_cur = s_cid2[par];
                 const double* hprev = s_h2[par ^ 1];
-                const int* muprev = s_mu2[par ^ 1];
-                tdm = __builtin_amdgcn_s_memrealtime();
-                // (A) this block's gradients: gxc as the rows left it, then the moves of the block before, in visit order
+                const bool more = ch + 1 < nch;
+                if (more && part == 1) stage_ids(par ^ 1, j0 + B);            // the next block's ids, for its gather during this block's visits
+                // (A) this block's gradients: as the rows / the helpers left them, then the moves of the block before, in visit order
+                double tv_[B / kCsWaves];
                 if (pend_n > 0) {
-                    double tv_[B / kCsWaves];
 #pragma unroll
-                    for (int r = 0; r < B / kCsWaves; ++r) tv_[r] = b.Gc[(size_t)muprev[min(part + kCsWaves * r, pend_n - 1)] * tcap + cid_cur[lane_t]];
+                    for (int r = 0; r < B / kCsWaves; ++r) {
+                        const int i = min(part + kCsWaves * r, pend_n - 1);
+                        tv_[r] = crewp ? b.Gcols[s_off2[(par ^ 1) * B + i] + s_k2[par * B + lane_t]] : b.Gc[(size_t)s_mu2[par ^ 1][i] * tcap + s_cid2[par][lane_t]];
+                    }
+                }
+                if (crewp) crew_wait(njobs > 0 ? njobs - 1 : 0);      // everything but the job just posted is finished (that one leaves this block's coordinates alone)
+                const double q_blk = s_ctrl.q_carry;
+                if (pend_n > 0) {
 #pragma unroll
                     for (int r = 0; r < B / kCsWaves; ++r) s_tile[(part + kCsWaves * r) * B + lane_t] = tv_[r];
                     __syncthreads();
                 }
                 if (tid < B) {
-                    double v = b.gxc[cid_cur[tid]];
+                    double* src = crewp ? b.g + s_k2[par * B + tid] : b.gxc + s_cid2[par][tid];
+                    double v = *src;
                     for (int i = 0; i < pend_n; ++i) v = fma(-hprev[i], s_tile[i * B + tid], v);
                     rec[R::OFF_C + tid] = tid < nb ? v : 0.0;
+                    if (crewp && pend_n > 0 && tid < nb) *src = v;
                 }
-                if (tid == 0) { rec[R::OFF_Q] = s_ctrl.q_carry; s_task = 0; }
+                if (tid == 0) { rec[R::OFF_Q] = q_blk; s_task = 0; }
                 __syncthreads();
-                dlap(0);
-                // (B) wave 0 visits; the others bring gxc up to date with the block before; everybody has the next block's Gram entries on the way
-                const bool more = ch + 1 < nch;
-                if (more) gather_block(j0 + B);
-                if (more && part == 1) s_cid2[par ^ 1][lane_t] = b.ucid[min(j0 + B + lane_t, cnt - 1)];
+                // (B) wave 0 visits; table mode: the others bring gxc up to date with the block before; the next block's Gram entries are on the way
+                if (more) { gather_block(par ^ 1); store_block(recb(par ^ 1), min(B, cnt - j0 - B)); }
                 if (tid < 64) {
                     gram_scalar_body<4>(rec, nb, 0, &s_ctrl, T.beta, T.om, T.iota, T.hs, T.nv, T.tch, j0, T.qs, tid);
-                    dlap(1);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     const double hv = tid < nb ? T.hs[j0 + tid] : 0.0;
                     const bool nz = hv != 0.0;                       // (a NaN h counts as a move: the pass is then undone)
                     const unsigned long long mask = __ballot(nz);
-                    if (nz) { const int at = __popcll(mask & ((1ull << tid) - 1ull)); s_h2[par][at] = hv; s_mu2[par][at] = cid_cur[tid]; }
+                    if (nz) {
+                        const int at = __popcll(mask & ((1ull << tid) - 1ull));
+                        s_h2[par][at] = hv;
+                        if (crewp) { s_off2[par * B + at] = s_v2[par * B + tid]; s_pos2[par * B + at] = j0 + tid; s_q2[par * B + at] = sqrt_loss ? T.qs[j0 + tid] : 0.0; }
+                        else s_mu2[par][at] = s_cid2[par][tid];
+                    }
                     if (__ballot(hv != hv)) { if (tid == 0) s_nan = 1; }
                     double run = (hv == hv) ? fabs(hv) : 0.0;
 #pragma unroll
@@ -605,17 +826,23 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     if (tid == 0) s_nmove = __popcll(mask);
                     const double last = __shfl(run, 63, 64);
                     if (tid == 0) s_tvrun = base + last;
-                    dlap(2);
                 }
-                if (pend_n > 0) rows_update(hprev, muprev, pend_n);
-                if (more) store_block(recb(par ^ 1), min(B, cnt - j0 - B));
+                if (table && pend_n > 0) rows_update(hprev, s_mu2[par ^ 1], pend_n);
                 __syncthreads();
-                dlap(3);
                 pend_n = s_nmove;
+                // (C) crew: the block's moves go to the helpers (a block without moves is posted too: its job re-checks, and every job names
+                // the coordinates of the block after it as workgroup 0's own)
+                if (crewp) crew_post(kCrewUpdate, par, pend_n, j0, nb, 1, more ? 0 : 1, more ? j0 + B : -1, q_blk);
             }
-            if (tid == 0) s_task = 0;
-            __syncthreads();
-            if (pend_n > 0) rows_update(s_h2[(nch - 1) & 1], s_mu2[(nch - 1) & 1], pend_n);
+            if (table) {
+                if (tid == 0) s_task = 0;
+                __syncthreads();
+                if (pend_n > 0) rows_update(s_h2[(nch - 1) & 1], s_mu2[(nch - 1) & 1], pend_n);
+            } else {
+                crew_wait(njobs);
+                if (tid == 0 && cs_ld_acquire(&cw->bad) != 0) s_bad = 1;
+                crew_passes += 1;
+            }
             __syncthreads();
         }
         // what the p-sized loops below read by position: in global memory
@@ -630,7 +857,8 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         if (s_ctrl.domain_error) dom_any = 1;
 
         // ---- the settled positions, re-checked with the bound as it stood at their turn; exactly where the bound fails ----
-        if (full && cnt < L && (tv_pass > 0.0 || TV0 > 0.0)) {
+        if (crew_lost) { status = kCsCrewLost; break; }
+        if (full && cnt < L && (tv_pass > 0.0 || TV0 > 0.0) && !crewp) {      // (a crew pass: the helpers have re-checked on the way, with g itself)
             const int cm1 = cnt > 0 ? cnt - 1 : 0;
             for (int64_t k0 = 0; k0 < p; k0 += kCsThreads * E) {
                 int64_t k[E];
@@ -698,6 +926,15 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         if (full && cnt > 0 && inject_every > 0) { inject_count += 1; if (inject_count % inject_every == 0) { undo = true; injected = true; } }
         if (undo) {                       // the pass never happened (beta itself was not touched)
             rng = rng_before;
+            if (crewp && cnt > 0) {       // ... once g is what it was (the helpers had moved it along)
+                if (tid < 64) {
+                    CsCrewJob* job = &cw->ring[njobs & 1];
+                    if (tid == 0) { job->kind = kCrewRestore; job->nmove = 0; job->hold_tag = njobs + 1; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (tid == 0) cs_st_release(&cw->posted, njobs + 1);
+                }
+                njobs += 1; crew_jobs += 1;
+            }
             // coordinates that crossed their threshold through the pass's own moves: the same pass again with those on the visit list
             // (visiting more than necessary is always right); after a few such rounds, or for anything else, the host walks it the careful way
             if (crossed && !injected && s_nan == 0 && !(nzero > 0 && (TV0 > 0.0 || tv_pass > 0.0)) && forced_rounds_here < kCsForcedRounds) {
@@ -723,16 +960,18 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             const int uc = in ? u : 0;
             const int64_t k = cnt > 0 ? T.k[uc] : 0;
             const double hv = cnt > 0 ? b.hs[uc] : 0.0;
-            const bool neu[1] = {in && hv != 0.0 && b.inmoved[k] == 0};
+            const bool neu[1] = {in && hv != 0.0 && b.inmoved[k] == 0 && !crewp};      // (a crew pass leaves nothing pending on g)
             int at[1];
             const int tot = cs_rank<1>(neu, at, s_w);
             if (neu[0]) { b.moved[nmoved + at[0]] = (int32_t)k; b.inmoved[k] = 1; }
-            if (in) { b.gxp[k] = pass_id; b.gx[k] = table ? b.gxc[b.ucid[u]] : T.gx[u]; b.beta[k] = T.beta[u]; }
+            if (in && !crewp) { b.gxp[k] = pass_id; b.gx[k] = table ? b.gxc[b.ucid[u]] : T.gx[u]; }
+            if (in) { b.beta[k] = T.beta[u]; if (crewp) b.bfold[k] = T.beta[u]; }
             nmoved += tot;
         }
         pass_id += 1;
-        if (in_lds) tepoch += 1;          // (the table's gradients have not seen this pass's moves)
-        TV0 += tv_pass; q = q_end;
+        if (!table) tepoch += 1;          // (the table's gradients have not seen this pass's moves)
+        if (!crewp) TV0 += tv_pass;
+        q = q_end;
         __syncthreads();
         lap(5);
 
@@ -904,6 +1143,11 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
 
     // ---- what the host needs: the support in slot order with its values, the moves still pending on g ----
     __syncthreads();
+    if (crew) {                           // the helpers finish what is posted, then leave
+        crew_wait(njobs);
+        if (crew_lost) status = kCsCrewLost;
+        if (tid == 0) cs_st_release(&cw->exit_flag, 1u);
+    }
     if (forced_dirty) for (int64_t k = tid; k < p; k += kCsThreads) b.forced[k] = 0;
     for (int s = tid; s < nnz; s += kCsThreads) { const int k = b.s2i[s]; b.out_sup_idx[s] = k; b.out_sup_val[s] = b.beta[k]; }
     for (int m = tid; m < nmoved; m += kCsThreads) { const int km = b.moved[m]; b.out_moved_idx[m] = km; b.out_moved_val[m] = b.beta[km] - b.bfold[km]; }
@@ -917,14 +1161,13 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     }
     if (tid == 0) {
         ctl->rng = rng; ctl->q = q; ctl->nnz = nnz; ctl->prev_conv = prev_conv ? 1 : 0; ctl->conv = conv ? 1 : 0;
-        ctl->ncid = ncid; ctl->tepoch = tepoch; ctl->table_passes = table_passes; ctl->table_rows = table_rows; ctl->forced_rounds = forced_rounds;
+        ctl->ncid = ncid; ctl->tepoch = tepoch; ctl->table_passes = table_passes; ctl->table_rows = table_rows; ctl->forced_rounds = forced_rounds; ctl->crew_passes = crew_passes; ctl->crew_jobs = crew_jobs;
         ctl->inject_count = inject_count; ctl->status = status; ctl->n_list = n_list; ctl->n_moved = nmoved;
         ctl->domain_error = dom_any; ctl->passes = passes; ctl->full_passes = full_passes; ctl->visits = visits;
         ctl->cov_visits = cov_visits; ctl->cov_visits_full = cov_visits_full; ctl->settled = settled_total; ctl->folds = folds; ctl->exact_rechecks = exact_rechecks;
         ctl->maxH = lastH;
         lap(7);
         for (int i = 0; i < 8; ++i) ctl->ticks[i] = (int64_t)tph[i];
-        for (int i = 0; i < 4; ++i) ctl->dbg[i] = (int64_t)tdbg[i];
         ctl->cycles = (int64_t)(__builtin_amdgcn_s_memtime() - cyc0); ctl->ticks_total = (int64_t)(__builtin_amdgcn_s_memrealtime() - tick0);
     }
 }
@@ -951,7 +1194,8 @@ int32_t cs_alloc(cdh_handle h) {
     const size_t p = (size_t)h->p;
     const size_t tc = (size_t)kCsTableCap;
     const size_t dev_bytes = 11 * cs_align(8 * p) + 5 * cs_align(8 * p) + 12 * cs_align(4 * p) + 3 * cs_align(p) + cs_align(8 * p) /* colmax */ +
-                             cs_align(8 * tc * tc) + 2 * cs_align(8 * tc) + cs_align(4 * tc) + 3 * cs_align(4 * p) /* the Gram table */;
+                             cs_align(8 * tc * tc) + 2 * cs_align(8 * tc) + cs_align(4 * tc) + 3 * cs_align(4 * p) /* the Gram table */ +
+                             cs_align(sizeof(CsCrew)) + cs_align(8 * p) + cs_align(4 * p) /* the crew: jobs, g's snapshot, the hold tags */;
     const size_t pin_bytes = cs_align(sizeof(CovSolveCtl)) + 4 * cs_align(4 * p) + 2 * cs_align(8 * p);
     void* dev_view = nullptr;
     bool fits = hipMalloc((void**)&c.cs_dev, dev_bytes) == hipSuccess && hipHostMalloc((void**)&c.cs_pin, pin_bytes) == hipSuccess &&
@@ -983,6 +1227,7 @@ int32_t cs_alloc(cdh_handle h) {
     b.Gc = (double*)take(8 * tc * tc); b.gxc = (double*)take(8 * tc); b.cidk = (int64_t*)take(8 * tc); b.gxe = (int32_t*)take(4 * tc);
     b.cidof = (int32_t*)take(4 * p); b.ucid = (int32_t*)take(4 * p); b.newc = (int32_t*)take(4 * p);
     c.cs_ncid = 0; c.cs_table_reset = true;
+    b.crew = (CsCrew*)take(sizeof(CsCrew)); b.g_snap = (double*)take(8 * p); b.hold = (uint32_t*)take(4 * p);
     // the pinned block, as the host and as the device address it
     size_t o = cs_align(sizeof(CovSolveCtl));
     auto pin = [&](size_t bytes) { const size_t at = o; o += cs_align(bytes); return at; };
@@ -1076,8 +1321,11 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     // Full passes of large supports stay with the host's device pass (gc_pass_device): certifying the inactive coordinates takes g
     // for all p after every block of moves -- p x moves gathers per pass, which twenty workgroups do in microseconds and one does not
     // (the bound of the loop's certificates is useless there: M_k TV exceeds the thresholds themselves once hundreds of coordinates move)
+    // ... unless the launch brings helpers (the crew, above): then they do that work beside the visits, inside the loop
     static const int full_env = cs_env_int("CDH_CS_FULL_CAP", 0);
-    const int32_t full_cap = full_env > 0 ? full_env : ucap - kCsTrackedMargin;
+    const int crew_env = c.cs_helpers;
+    const int nhelp = (crew_env > 0 && table_on && h->x.nnz() + kCsTrackedMargin / 2 > ucap - kCsTrackedMargin) ? std::min(crew_env, kCsCrewMax) : 0;
+    const int32_t full_cap = full_env > 0 ? full_env : (nhelp > 0 ? 0x7fffffff : ucap - kCsTrackedMargin);
     if (full && h->x.nnz() > full_cap) return not_now();
     if (c.cs_table_reset) {          // a new X: the table's entries are void
         HIPCHK(h, hipMemsetAsync(c.cs_bufs.cidof, 0xff, sizeof(int32_t) * (size_t)h->p, h->stream));
@@ -1124,7 +1372,9 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     if (ctl.tcap == 0 && h->x.nnz() > ucap - kCsTrackedMargin) return not_now();     // (the budget the runtime really granted is smaller)
     const unsigned lds = (unsigned)(8 * cs_tri_doubles((size_t)ucap) + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes);
     if (o->randomize && 24 * ((size_t)h->p + 1) > (size_t)lds) return not_now();   // the shuffle's scratch overlays the dynamic LDS
-    hipLaunchKernelGGL(k_cov_solve, dim3(1), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
+    const int nh = ctl.tcap > 0 ? nhelp : 0;
+    if (nh > 0) HIPCHK(h, hipMemsetAsync(b.crew, 0, sizeof(CsCrew), h->stream));
+    hipLaunchKernelGGL(k_cov_solve, dim3(1 + nh), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     c.n_cs_launches += 1;
@@ -1162,14 +1412,14 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
         if (!c.in_moved[(size_t)k]) { c.in_moved[(size_t)k] = 1; c.moved.push_back(k); }
     }
     c.cs_ncid = ctl.ncid; c.cs_tepoch = ctl.tepoch; c.n_cs_table_passes += ctl.table_passes; c.n_cs_table_rows += ctl.table_rows;
-    c.n_cs_forced_rounds += ctl.forced_rounds;
+    c.n_cs_forced_rounds += ctl.forced_rounds; c.n_cs_crew_passes += ctl.crew_passes; c.n_cs_crew_jobs += ctl.crew_jobs;
+    if (ctl.crew_passes > 0) c.g_host_ok = false;       // the helpers have moved d_g along
     if (ctl.folds > 0) c.g_host_ok = false;
     if (h->loss == CDH_SQRT) c.q = ctl.q;
     c.inject_count = ctl.inject_count;
     c.n_passes += ctl.full_passes; c.n_dev_passes += ctl.full_passes; c.n_certified += ctl.settled;
     c.n_cov += ctl.cov_visits; c.cov_since_ref += ctl.cov_visits; c.n_cs_passes += ctl.passes; c.n_cs_folds += ctl.folds; c.n_cs_exact += ctl.exact_rechecks;
     for (int i = 0; i < 8; ++i) c.cs_ticks[i] += ctl.ticks[i];
-    for (int i = 0; i < 4; ++i) c.cs_dbg[i] += ctl.dbg[i];
     c.cs_cycles += ctl.cycles; c.cs_ticks_total += ctl.ticks_total;
     c.n_exact += ctl.cov_visits_full;
     if (ctl.domain_error) h->domain_error = true;
@@ -1186,6 +1436,7 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     case kCsRefresh: CHK(gc_rereference(h)); *outcome = kCsAgain; return CDH_OK;
     case kCsNeedQ: c.q_valid = false; CHK(gc_ensure_q(h)); *outcome = kCsAgain; return CDH_OK;
     case kCsNeedFold: gc_fold(h); *outcome = kCsAgain; return CDH_OK;
+    case kCsCrewLost: return fail(h, CDH_HIP_ERROR, "the device-resident solve lost its helper workgroups (a wait ran into its 20 s bound)");
     case kCsHostFull: return CDH_OK;                                // the next (full) pass runs the pass-by-pass way
     case kCsBusy:     // many inactive coordinates about to move: back off (1, 2, 4 ... 16 plain passes), as gc_pass_device does
         c.cooldown = c.backoff; c.backoff = std::min(16, 2 * c.backoff);

@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-enum { kCsConverged = 0, kCsMaxIter = 1, kCsNeedColumns = 2, kCsRollback = 3, kCsBusy = 4, kCsRefresh = 5, kCsOutgrown = 6, kCsNeedQ = 7, kCsNeedFold = 8, kCsHostFull = 9 };
+enum { kCsConverged = 0, kCsMaxIter = 1, kCsNeedColumns = 2, kCsRollback = 3, kCsBusy = 4, kCsRefresh = 5, kCsOutgrown = 6, kCsNeedQ = 7, kCsNeedFold = 8, kCsHostFull = 9, kCsCrewLost = 10 };
 
 struct CovSolveCtl {
     // in
@@ -24,11 +24,28 @@ struct CovSolveCtl {
     int32_t ncid, tepoch;        // the table: coordinates it holds (kept from launch to launch), the epoch its carried gradients belong to
     // out
     int32_t status, n_list /* kCsNeedColumns / kCsBusy: coordinates that want a Gram column (out_list) */, n_moved, domain_error;
-    int64_t passes, full_passes, visits, cov_visits, cov_visits_full, settled, folds, exact_rechecks, table_passes, table_rows, forced_rounds;
+    int64_t passes, full_passes, visits, cov_visits, cov_visits_full, settled, folds, exact_rechecks, table_passes, table_rows, forced_rounds, crew_passes, crew_jobs;
     double maxH;
     int64_t cycles, ticks_total; // shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) the launch ran for
-    int64_t dbg[4];              // (experiments: ticks inside the visits phase -- staging a block, its visits, the gradient update)
     int64_t ticks[8];            // 100 MHz ticks the kernel spent per phase (list, scan, exact gradients, visits, re-check, accept, bookkeeping, dropzeros! + the rest)
+};
+
+// The crew: helper workgroups of the same launch that keep g = X'r current for ALL p coordinates while workgroup 0 visits
+// (cov_solve.hpp, "crew passes").  Workgroup 0 posts one job per block of visits; the helpers take them in order.
+constexpr int kCsCrewMax = 64;
+enum { kCrewUpdate = 1, kCrewSnapshot = 2, kCrewRestore = 3, kCrewFold = 4 };
+struct CsCrewJob {
+    int32_t kind, nmove, j0, nb, chk, last_block, cnt, pad;
+    uint32_t hold_tag, pad1;
+    double q_start;
+    double h[64], q[64];
+    int64_t off[64];
+    int32_t pos[64];
+};
+struct CsCrew {
+    uint32_t posted, exit_flag, bad, lost;
+    uint32_t done[kCsCrewMax];
+    CsCrewJob ring[2];
 };
 
 struct CovSolveBufs {
@@ -43,6 +60,10 @@ struct CovSolveBufs {
     double *Gc, *gxc;
     int64_t* cidk;
     int32_t *cidof, *ucid, *gxe, *newc;
+    // crew passes
+    CsCrew* crew;
+    double* g_snap;
+    uint32_t* hold;
     const int32_t* in_sup;                   // the support in slot order (pinned host memory, read once)
     int32_t *out_sup_idx, *out_moved_idx, *out_list;   // pinned host memory, written once at the end
     double *out_sup_val, *out_moved_val;

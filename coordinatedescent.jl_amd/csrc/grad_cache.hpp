@@ -620,7 +620,6 @@ int32_t gc_fetch_entering(cdh_handle h, std::vector<int64_t>& enter, Cert&& cert
 // test_covariance_chunks_roll_back...) restores g and beta from the scan's snapshot and leaves the pass to the
 // windowed walk below, which knows how to stop at the offending position.
 enum { kDevDone = 0, kDevPlain = 1, kDevWalk = 2 };
-double g_dbg_book_us = 0, g_dbg_scan_us = 0, g_dbg_blocks_us = 0;
 constexpr int kGcForcedRounds = 4;     // a device pass whose re-check failed is run again this often with the failing coordinates visited
 template <typename Cert, typename Ratio>
 int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* maxH, double cert_abs, Cert&& cert, Ratio&& ratio,
@@ -657,10 +656,8 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
         hipLaunchKernelGGL(k_cov_scan, dim3(1), dim3(1024), 0, h->stream, c.d_g, c.d_a, h->beta, h->omega, h->d_ctrl, c.d_pass_idx, (int)m,
                            h->p, c.d_pos_of, c.d_setflag, c.d_upos, h->d_idx, c.d_g_snap, c.d_beta_snap, c.d_scan, c.d_forced);
         HIPCHK(h, hipGetLastError());
-        const auto dbg_s0 = std::chrono::steady_clock::now();
         HIPCHK(h, hipMemcpyAsync(c.h_scanbuf, c.d_scanbuf, sizeof(int32_t) * (size_t)(m + 4), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        g_dbg_scan_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_s0).count();
         cnt = c.h_scan->count;
         if (c.h_scan->nzero > 0) return CDH_OK;     // a settled coordinate with g == 0 exactly: its bookkeeping differs; the walk knows
         std::vector<int64_t> enter;
@@ -683,11 +680,9 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
     c.backoff = 1;
     if (cnt > 0) {
         h->chunk_dup = false;
-        const auto dbg_k0 = std::chrono::steady_clock::now();
         CHK(launch_cov_blocks(h, cnt, true, (int)m));
         HIPCHK(h, hipGetLastError());
         CHK(cov_fetch_results(h, cnt, true));
-        g_dbg_blocks_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_k0).count();
         // (tests: CDH_GC_INJECT_ROLLBACK=N declares every N-th device pass failed after the fact, so that the undo and the
         // windowed walk that takes over are exercised on every problem of the suite, not only where a certificate breaks)
         const bool injected = c.inject_rollback > 0 && (++c.inject_count % c.inject_rollback) == 0;
@@ -711,7 +706,6 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
     break;
   }
     // bookkeeping in visit order: what the reference's SparseIterate would have seen
-    const auto dbg_b0 = std::chrono::steady_clock::now();
     int j = 0;
     for (int64_t q = 0; q < m; ++q) {
         const int64_t k = idx0[q];
@@ -723,7 +717,6 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
     }
     c.n_exact += cnt; c.n_certified += m - cnt; c.n_dev_passes += 1;
     cov_accept_tail(h, cnt, maxH, false);
-    g_dbg_book_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_b0).count();
     *outcome = kDevDone;
     return CDH_OK;
 }

@@ -240,16 +240,20 @@ int32_t cdh_cache_stats(cdh_handle h, int64_t *out10);
  * gradient, certificates re-checked with the exact gradient because the bound did not cover them, and the time the kernel
  * spent per phase in 10 ns ticks: building visit lists, the scan, exact gradients of the visited coordinates, the visits,
  * the re-check, accepting a pass, the SparseIterate bookkeeping, dropzeros! and the rest}. */
-int32_t cdh_set_device_loop(cdh_handle h, int32_t on);
+int32_t cdh_set_device_loop(cdh_handle h, int32_t on);   /* 0: off; 1: on; 2: on, without helper workgroups; n > 2: on, with n helpers (at most 64) */
 int32_t cdh_device_loop_stats(cdh_handle h, int64_t *out12);
 /* Visit lists beyond the loop's LDS-sized Gram block (~150 non-zeros) run from a Gram TABLE in device memory: X_j'X_k by
  * table id for every coordinate the loop has visited, filled from the cached columns as coordinates enter and kept from
  * solve to solve, with the exact gradient of every coordinate it holds carried through each block of visits (rows of the
- * table: contiguous).  out6 = {passes run in table mode, table rows filled, coordinates the table holds, its capacity,
+ * table: contiguous).  out8 = {passes run in table mode, table rows filled, coordinates the table holds, its capacity,
  * and how often a full pass whose re-check found coordinates crossing their threshold through the pass's own moves was
  * run again with those coordinates visited (instead of being walked position by position): by the host's device pass, by
- * the loop itself}. */
-int32_t cdh_device_loop_table(cdh_handle h, int64_t *out6);
+ * the loop itself}.
+ * Launches that expect such lists bring HELPER workgroups (the crew; CDH_CS_CREW = their number, default 31, 0: none): they
+ * keep the gradient current for all p coordinates while workgroup 0 visits, and re-check the skipped coordinates of full
+ * passes on the way, so that full passes of large supports stay in the loop too; out8[6..7] = {passes run with the crew,
+ * jobs it was given}. */
+int32_t cdh_device_loop_table(cdh_handle h, int64_t *out8);
 /* How far the carried gradient has been from X'r whenever it was taken afresh from X (after CDH_GC_REFRESH
  * covariance-form visits, or right now with rereference_now != 0: one dots-only pass over X):
  *   drift = max_k |g_carried[k] - X_k'r| / thr_k,   thr_k = lambda0 n omega_k (sqrt-lasso: lambda0 omega_k ||r||)

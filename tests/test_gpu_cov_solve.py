@@ -175,10 +175,13 @@ def test_sqrt_lasso_near_noiseless_keeps_its_residual_norm(loop):
 @pytest.mark.parametrize("kind,rand", [("ls", False), ("ls", True), ("sqrt", False), ("wl1", True)],
                          ids=["ls-ordered", "ls-random", "sqrt-ordered", "wl1-random"])
 def test_device_loop_table_mode_on_large_supports(kind, rand):
-    """Visit lists beyond the LDS-sized Gram block (~150 non-zeros; benchmark/cd_bench.jl's path ends at 774): the loop
-    reads X_j'X_k from its Gram table in device memory and carries the exact gradient of every coordinate the table holds.
-    A warm-started path whose support grows from ~100 to ~500 non-zeros (and shrinks again at the end: the last lambda is
-    larger), every lambda against the oracle with the same passes, visits and support order; then the loop off."""
+    """Visit lists beyond the LDS-sized Gram block (~150 non-zeros; benchmark/cd_bench.jl's path ends at 774).  Active passes:
+    the loop reads X_j'X_k from its Gram table in device memory and carries the exact gradient of every coordinate the table
+    holds.  Full passes: with helper workgroups in the launch (the default) they keep g current for all p and re-check the
+    skipped coordinates while workgroup 0 visits; without, the host's device pass runs them.
+    A warm-started path whose support grows from ~180 to ~370 non-zeros (and shrinks again at the end: the last lambda is
+    larger), every lambda against the oracle with the same passes, visits and support order -- with helpers, with one
+    workgroup, with the loop off."""
     rng, X, Y = _problem(97, 1600, 1400, 300, noise=2.0)
     om = (rng.random(1400) + 0.5) if kind == "wl1" else None
     if kind == "sqrt":
@@ -195,29 +198,37 @@ def test_device_loop_table_mode_on_large_supports(kind, rand):
     sizes = [len(w[1]) for w in want]
     assert max(sizes) > 300 and min(sizes) < 250, sizes
     got = {}
-    for loop in (True, False):
+    for mode in ("helpers", "one workgroup", "host loop"):
         f = cd.CDSqrtLassoLoss(Y, X) if kind == "sqrt" else cd.CDLeastSquaresLoss(Y, X)
         f.set_gradient_cache(3)
         f.set_onchip_solve(False)
-        f.set_device_loop(loop)
+        if mode == "helpers":
+            f.set_device_loop(True)                   # the default: launches that expect large lists bring 31 helper workgroups
+        elif mode == "one workgroup":
+            f.set_device_loop(True, helpers=0)        # table mode only; full passes of large supports go to the host's device pass
+        else:
+            f.set_device_loop(False)
         x, rec = cd.SparseIterate(1400), []
         for lam, (beta, sup, passes, visits) in zip(lams, want):
             cd.coordinateDescent_(x, f, cd.ProxL1(lam, om), cd.CDOptions(**o))
             np.testing.assert_allclose(x.dense(), beta, rtol=0, atol=BETA_TOL)
-            assert x.nzval2ind.tolist() == sup, (loop, lam)
-            assert (f.last_stats["passes"], f.last_stats["visits"]) == (passes, visits), (loop, lam)
+            assert x.nzval2ind.tolist() == sup, (mode, lam)
+            assert (f.last_stats["passes"], f.last_stats["visits"]) == (passes, visits), (mode, lam)
             rec.append(x.dense().copy())
         np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-8)
         ls = f.device_loop_stats()
-        if loop:
-            assert ls["table"]["passes"] > 30 and ls["table"]["rows_filled"] > 200, ls
+        if mode == "helpers":
+            assert ls["table"]["passes"] > 30 and ls["crew"]["passes"] > 5 and ls["crew"]["jobs"] > 3 * ls["crew"]["passes"], ls
+        elif mode == "one workgroup":
+            assert ls["table"]["passes"] > 30 and ls["table"]["rows_filled"] > 200 and ls["crew"]["passes"] == 0, ls
             assert ls["table"]["coordinates"] <= ls["table"]["capacity"]
         else:
-            assert ls["launches"] == 0 and ls["table"]["passes"] == 0
-        got[loop] = rec
+            assert ls["launches"] == 0 and ls["table"]["passes"] == 0 and ls["crew"]["passes"] == 0
+        got[mode] = rec
         f.close()
-    for a, b_ in zip(got[True], got[False]):
-        np.testing.assert_allclose(a, b_, rtol=0, atol=1e-11)
+    for other in ("one workgroup", "host loop"):
+        for a, b_ in zip(got["helpers"], got[other]):
+            np.testing.assert_allclose(a, b_, rtol=0, atol=1e-11)
 
 
 def test_device_loop_table_survives_a_new_X_and_an_overflow(monkeypatch):
@@ -248,4 +259,36 @@ def test_device_loop_table_survives_a_new_X_and_an_overflow(monkeypatch):
         np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
         assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"], lam
     assert f.device_loop_stats()["table"]["passes"] > t0["passes"]
+    f.close()
+
+
+@pytest.mark.parametrize("inject", [0, 2], ids=["as it comes", "every second full pass undone"])
+def test_device_loop_helpers_undo_a_full_pass_and_restore_the_gradient(inject, monkeypatch):
+    """A full pass run with the helpers moves g itself along; when it has to be undone -- coordinates crossed their threshold
+    through the pass's own moves (correlated columns: corr(X_j, X_j+1) = 0.9), or the test says so (CDH_GC_INJECT_ROLLBACK) --
+    the helpers put g back as the pass found it (the snapshot job at its start), and the pass runs again with the crossing
+    coordinates visited, or is left to the host's careful walk.  Supports of 120-320 non-zeros; the oracle's iterates, support
+    order and pass counts at every lambda."""
+    if inject:
+        monkeypatch.setenv("CDH_GC_INJECT_ROLLBACK", str(inject))
+    rng, X, Y = _problem(103, 1500, 1300, 260, noise=1.5, rho=0.9)
+    lams = np.exp(np.linspace(np.log(0.25), np.log(0.04), 10))
+    o = dict(maxIter=20000, optTol=1e-9, randomize=False)
+    f, fo = cd.CDLeastSquaresLoss(Y, X), O.CDLeastSquaresLoss(Y, X)
+    f.set_gradient_cache(3)
+    f.set_onchip_solve(False)
+    x, xo = cd.SparseIterate(1300), O.SparseIterate(1300)
+    sizes = []
+    for lam in lams:
+        st = O.coordinateDescent_(xo, fo, O.ProxL1(lam), O.CDOptions(**o))
+        cd.coordinateDescent_(x, f, cd.ProxL1(lam), cd.CDOptions(**o))
+        np.testing.assert_allclose(x.dense(), xo.dense(), rtol=0, atol=BETA_TOL)
+        assert x.nzval2ind.tolist() == xo.nzval2ind.tolist() and f.last_stats["passes"] == st["passes"], lam
+        sizes.append(x.nnz)
+    assert max(sizes) > 200, sizes
+    ls, cs = f.device_loop_stats(), f.cache_stats()
+    assert ls["crew"]["passes"] > 0 and ls["crew"]["jobs"] > 0, ls
+    if inject:
+        assert cs["rollbacks"] > 0, cs
+    np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-8)
     f.close()

@@ -67,9 +67,12 @@ def _switch_paths(rng, f, log):
         f.set_use_graph(on)
         log.append(f"graph {on}")
     else:
-        on = bool(rng.integers(0, 3))                  # (off one time in three: the pass loop of cache-served solves on the host)
-        f.set_device_loop(on)
-        log.append(f"device loop {on}")
+        how = int(rng.integers(0, 4))                  # off one time in four (the pass loop on the host); else with helper
+        if how == 0:                                   # workgroups for large visit lists (the default), without, or with few
+            f.set_device_loop(False)
+        else:
+            f.set_device_loop(True, helpers=[None, 0, 5][how - 1])
+        log.append(f"device loop {how}")
 
 
 def _check_iterates(x, xo, log, strict_order=True):
