@@ -141,6 +141,7 @@ struct GradCache {
             n_reconcile = 0;
     // the device-resident pass loop (cov_solve.hpp): its scratch, the pinned block it reads from and writes into, the bound's M_k
     bool cs_enabled = true;          // env CDH_COV_SOLVE (default 1)
+    int cs_ucap_limit = 0;           // env CDH_CS_UCAP (tests): visit lists longer than this leave the LDS block
     int cs_helpers = 31;             // helper workgroups a launch that expects large visit lists brings (env CDH_CS_CREW; 0: none, table mode only)
     bool cs_shuffle_ok = true, cs_stalled = false;
     size_t cs_lds_budget = 0;
@@ -1242,6 +1243,7 @@ int32_t cdh_create(cdh_handle* out, int32_t dtype, int32_t loss, int64_t n_local
         h->gc.cov = env_int("CDH_GC_COV", 1) != 0;
         h->gc.cs_enabled = env_int("CDH_COV_SOLVE", 1) != 0;
         h->gc.cs_helpers = std::max(0, std::min(kCsCrewMax, env_int("CDH_CS_CREW", 31)));
+        h->gc.cs_ucap_limit = std::max(0, env_int("CDH_CS_UCAP", 0));
         h->small.enabled = env_int("CDH_SMALL_PATH", 1) != 0;
         if (const char* e = getenv("CDH_SMALL_MAX_BYTES")) h->small.max_bytes = std::atoll(e);
         h->small.zero_copy = env_int("CDH_SMALL_ZEROCOPY", 1) != 0;

@@ -276,6 +276,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     auto lap = [&](int ph) { const uint64_t now = __builtin_amdgcn_s_memrealtime(); tph[ph] += now - tmark; tmark = now; };
     int nnz = ctl->nnz, inject_count = ctl->inject_count;
     const int tcap = ctl->tcap, fold_limit = ctl->fold_limit, full_cap = ctl->full_cap;
+    const int ucap_lists = ctl->ucap_limit > 0 ? min(ucap, ctl->ucap_limit) : ucap;      // the longest visit list that runs from the LDS block
     int ncid = ctl->ncid, tepoch = ctl->tepoch + 1;      // (gradients the table carried belong to the launch that carried them)
     int64_t table_passes = 0, table_rows = 0, forced_rounds = 0, crew_passes = 0, crew_jobs = 0;
     const int nhelp = (int)gridDim.x - 1;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         if (full && nnz > full_cap && !crew) { status = kCsHostFull; break; }
         if (crew) {
             crew_wait(njobs);                                       // g is as current as the jobs posted so far make it
-            if (full && nmoved > 0 && nnz + kCsTrackedMargin > ucap) {
+            if (full && nmoved > 0 && nnz + kCsTrackedMargin > ucap_lists) {
                 // a full pass of a large support is a crew pass (below): the moves the table-mode passes have left pending are folded
                 // into g first -- p x moves gathers, the helpers' work
                 stage_pending();
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         // ---- the visited ("tracked") coordinates: beta, omega, their exact gradient (carried from the pass before where it was
         // kept current there, else g - sum_m pend_m G_m), their Gram block ----
         stage_pending();
-        const bool in_lds = cnt <= ucap;
+        const bool in_lds = cnt <= ucap_lists;
         const bool crewp = crew && !in_lds && full;      // a full pass over a visit list beyond the LDS-sized Gram block, helpers present: a crew pass
         const bool table = !in_lds && !crewp;    // ... no helpers: the Gram TABLE in device memory (see k_cov_solve's header)
         if (table && cnt > tcap) { status = kCsOutgrown; rng = rng_before; break; }
@@ -1324,8 +1325,10 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     // ... unless the launch brings helpers (the crew, above): then they do that work beside the visits, inside the loop
     static const int full_env = cs_env_int("CDH_CS_FULL_CAP", 0);
     const int crew_env = c.cs_helpers;
-    const int nhelp = (crew_env > 0 && table_on && h->x.nnz() + kCsTrackedMargin / 2 > ucap - kCsTrackedMargin) ? std::min(crew_env, kCsCrewMax) : 0;
-    const int32_t full_cap = full_env > 0 ? full_env : (nhelp > 0 ? 0x7fffffff : ucap - kCsTrackedMargin);
+    const int ucap_lists = c.cs_ucap_limit > 0 ? std::min(ucap, c.cs_ucap_limit) : ucap;
+    const int lds_margin = std::min(kCsTrackedMargin, ucap_lists / 4);
+    const int nhelp = (crew_env > 0 && table_on && h->x.nnz() + lds_margin / 2 > ucap_lists - lds_margin) ? std::min(crew_env, kCsCrewMax) : 0;
+    const int32_t full_cap = full_env > 0 ? full_env : (nhelp > 0 ? 0x7fffffff : ucap_lists - lds_margin);
     if (full && h->x.nnz() > full_cap) return not_now();
     if (c.cs_table_reset) {          // a new X: the table's entries are void
         HIPCHK(h, hipMemsetAsync(c.cs_bufs.cidof, 0xff, sizeof(int32_t) * (size_t)h->p, h->stream));
@@ -1355,7 +1358,7 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
         ctl.nnz_limit = (int32_t)std::min<int64_t>({lim, support_cap, (int64_t)0x7fffffff});
     }
     ctl.busy_limit = kGcBusy; ctl.inject_every = c.inject_rollback; ctl.fold_limit = fold_limit;
-    ctl.tcap = table_on ? kCsTableCap : 0; ctl.ncid = c.cs_ncid; ctl.tepoch = c.cs_tepoch; ctl.full_cap = full_cap; ctl.pad0 = 0;
+    ctl.tcap = table_on ? kCsTableCap : 0; ctl.ncid = c.cs_ncid; ctl.tepoch = c.cs_tepoch; ctl.full_cap = full_cap; ctl.ucap_limit = c.cs_ucap_limit;
     ctl.rng = sched.state(); ctl.q = c.q; ctl.q_floor = h->loss == CDH_SQRT ? kGcQGuard * c.q_exact : 0.0;
     ctl.nnz = (int32_t)h->x.nnz(); ctl.prev_conv = *prev_conv ? 1 : 0; ctl.conv = *conv ? 1 : 0; ctl.inject_count = c.inject_count;
     ctl.status = -1; ctl.n_list = 0;

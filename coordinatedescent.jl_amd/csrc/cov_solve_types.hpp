@@ -16,7 +16,7 @@ struct CovSolveCtl {
     int32_t fold_limit;          // pending moves beyond which a fold is the host's (p x moves gathers: one CU against the chip): kCsNeedFold
     int32_t tcap;                // rows of the tracked coordinates' Gram TABLE in device memory (0: none)
     int32_t full_cap;            // supports beyond this have their FULL passes run by the host (p x moves work per pass: the chip's, not one CU's)
-    int32_t pad0;
+    int32_t ucap_limit;          // > 0: visit lists longer than this leave the LDS block even where it would hold them (tests: small problems then exercise the table and the helpers)
     // in / out
     uint64_t rng;
     double q;                    // r'r (sqrt-lasso)

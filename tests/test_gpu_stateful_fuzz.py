@@ -103,10 +103,13 @@ def run_sequence(seed, setenv, ctx):
     if rng.integers(0, 3) == 0:
         setenv("CDH_GC_INJECT_ROLLBACK", str(int(rng.integers(1, 4))))  # device-side cache passes undone
     setenv("CDH_SMALL_ALWAYS_BYTES", ["16777216", "16777216", "0"][int(rng.integers(0, 3))])   # 0: the handle rents before it builds G
+    # the device loop's LDS block holds ~170 coordinates: far more than these problems' supports.  One sequence in three caps it at
+    # 6 or 12, so that their visit lists run from the loop's Gram table and, in full passes, with its helper workgroups
+    setenv("CDH_CS_UCAP", ["0", "0", "6", "12"][int(rng.integers(0, 4))])
     X = np.asfortranarray(rng.standard_normal((n, p)) * rng.uniform(0.4, 2.5, size=p))
     Y = X[:, :s] @ rng.standard_normal(s) + rng.uniform(0.3, 2.0) * rng.standard_normal(n)
     w = rng.uniform(0.5, 1.5, size=n) if kind == "wls" else None
-    log = [f"seed={seed} kind={kind} n={n} p={p} env={ {k: os.environ.get(k) for k in ('CDH_SMALL_PATH', 'CDH_SMALL_ALWAYS_BYTES', 'CDH_GC_REFRESH', 'CDH_GC_INJECT_ROLLBACK')} }"]
+    log = [f"seed={seed} kind={kind} n={n} p={p} env={ {k: os.environ.get(k) for k in ('CDH_SMALL_PATH', 'CDH_SMALL_ALWAYS_BYTES', 'CDH_GC_REFRESH', 'CDH_GC_INJECT_ROLLBACK', 'CDH_CS_UCAP')} }"]
 
     def oracle_loss():
         if kind == "sqrt":
@@ -256,7 +259,10 @@ def run_sequence(seed, setenv, ctx):
                 O.initialize_(fo, xo)
                 log.append("new observation weights")
         _switch_paths(rng, f, log)
-    for k, v in dict(f.cache_stats(), onchip_solves=f.onchip_stats()["solves"], sequences=1).items():
+    ls = f.device_loop_stats()
+    for k, v in dict(f.cache_stats(), onchip_solves=f.onchip_stats()["solves"], sequences=1, loop_launches=ls["launches"], loop_passes=ls["passes"],
+                     loop_table_passes=ls["table"]["passes"], loop_helper_passes=ls["crew"]["passes"], loop_helper_jobs=ls["crew"]["jobs"],
+                     loop_passes_run_again=ls["forced_rounds"]["loop"], host_passes_run_again=ls["forced_rounds"]["host_pass"]).items():
         REACHED[k] = REACHED.get(k, 0) + int(v)
     f.close()
 
@@ -358,7 +364,7 @@ def test_the_sequences_reached_the_paths_that_carry_state():
     if REACHED.get("sequences", 0) < 24:
         pytest.skip("fewer than 24 sequences ran in this process")
     for key in ("onchip_solves", "passes", "device_passes", "settled_visits", "covariance_visits", "residual_catchups",
-                "gram_batches", "reference_passes", "rollbacks"):
+                "gram_batches", "reference_passes", "rollbacks", "loop_launches", "loop_table_passes", "loop_helper_passes"):
         assert REACHED.get(key, 0) > 0, (key, REACHED)
     for key in ("fp32_onchip_solves", "fp32_passes", "fp32_covariance_visits", "fp32_gram_batches"):
         assert REACHED.get(key, 0) > 0, (key, REACHED)
