@@ -23,15 +23,17 @@ ref = None
 for mode in (1, 3, 0):
     f = cd.CDLeastSquaresLoss(Y, X)
     f.set_gradient_cache(mode)
-    for rep in range(2):
+    times = []
+    for rep in range(3):                      # the first run on a handle fetches the Gram columns (and, on the first handle, loads the kernels)
         t0 = time.perf_counter()
         path = cd.LassoPath(f, None, lams, cd.CDOptions(**o))
         f._L.cdh_synchronize(f._h)
-        tg = time.perf_counter() - t0
+        times.append(time.perf_counter() - t0)
+    tg = min(times[1:])
     b = path.betapath[-1].dense()
     if ref is None:
         ref = b
-    print("cache mode", mode, "path %.4f s" % tg, "nnz", path.betapath[-1].nnz, "max |dbeta| vs mode 1 %.2e" % float(np.max(np.abs(b - ref))),
+    print("cache mode", mode, "path %.4f s" % tg, "(first run on the handle %.4f s)" % times[0], "nnz", path.betapath[-1].nnz, "max |dbeta| vs mode 1 %.2e" % float(np.max(np.abs(b - ref))),
           f.cache_stats(), f.device_loop_stats(), flush=True)
     f.close()
 if os.environ.get("CPU"):
