@@ -32,9 +32,17 @@
 // one without a Gram column does) the kernel folds: g -= sum_m pend_m G_m over all p, TV = 0.
 // ProximalBase's bookkeeping without its p transient slots: the final slot order of a pass is assembled from the old slots
 // and the visited appenders only (see "analytic" below); the straightforward replay stays for the rare exceptions.
-// What it is NOT for: supports beyond the LDS-sized Gram block (~150 non-zeros).  There every visit's update of the tracked
-// gradients is a gather through ONE CU (0.38 s against 0.11 s for the pass-by-pass kernels at benchmark/cd_bench.jl's shape,
-// 774 non-zeros): the host keeps those.
+// Visit lists beyond the LDS-sized Gram block (~150 non-zeros; benchmark/cd_bench.jl's path ends at 774): one CU cannot gather
+// p x moves Gram entries per block of visits (first attempt: 0.38 s against 0.11 s for the pass-by-pass kernels), so
+//   * ACTIVE passes run from a Gram TABLE in device memory: Gc[c][d] = X_k(c)' X_k(d) by table id for every coordinate the loop
+//     has visited (filled from the cached columns as coordinates enter, kept from solve to solve, void on a new X) and gxc[c],
+//     the exact gradient of every coordinate the table holds -- a block's moves update gxc through 64 contiguous rows of Gc;
+//   * FULL passes run with HELPER workgroups of the same launch ("the crew", below): they keep g = X'r itself current for all p
+//     coordinates and re-check every skipped coordinate at its turn while workgroup 0 visits (a launch without helpers leaves
+//     those passes to the host's device pass: kCsHostFull).
+// Both share one pipeline with two blocks of 64 visits in flight (see "Visit lists beyond the LDS block" in the kernel).
+// A full pass in which coordinates crossed their threshold through the pass's own moves runs again with those coordinates
+// visited (forced[], kCsForcedRounds) before anything is handed to the host.
 // Why it looks the way it does (measured, LAB_NOTES.md round 4): on one CU every dependent global access is 0.2-0.5 us, so
 // the p-sized loops issue all their loads unconditionally (clamped indices, no short-circuit conditions: a conditional load
 // is compiled into a load that is waited for on its own) and rank several flags per pair of barriers.
@@ -726,12 +734,22 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     if (c0 >= ncid) continue;
                     double4 acc = *reinterpret_cast<const double4*>(b.gxc + c0);
                     int i = 0;
-                    for (; i + 8 <= nmv; i += 8) {
-                        double4 rv[8];
+                    for (; i + 16 <= nmv; i += 16) {
+                        double4 rv[16];
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) rv[t] = *reinterpret_cast<const double4*>(b.Gc + (size_t)mub[i + t] * tcap + c0);
+                        for (int t = 0; t < 16; ++t) rv[t] = *reinterpret_cast<const double4*>(b.Gc + (size_t)mub[i + t] * tcap + c0);
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) {
+                        for (int t = 0; t < 16; ++t) {
+                            const double hv = -hb[i + t];
+                            acc.x = fma(hv, rv[t].x, acc.x); acc.y = fma(hv, rv[t].y, acc.y); acc.z = fma(hv, rv[t].z, acc.z); acc.w = fma(hv, rv[t].w, acc.w);
+                        }
+                    }
+                    for (; i + 4 <= nmv; i += 4) {
+                        double4 rv[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) rv[t] = *reinterpret_cast<const double4*>(b.Gc + (size_t)mub[i + t] * tcap + c0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
                             const double hv = -hb[i + t];
                             acc.x = fma(hv, rv[t].x, acc.x); acc.y = fma(hv, rv[t].y, acc.y); acc.z = fma(hv, rv[t].z, acc.z); acc.w = fma(hv, rv[t].w, acc.w);
                         }
@@ -1173,12 +1191,22 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     }
 }
 
-// M_k = max(M_k, |G_jk|) over one freshly cached column j (k != j): the bound of k_cov_solve's certificates
-__global__ __launch_bounds__(256) void k_cov_colmax(double* __restrict__ colmax, const double* __restrict__ col, int64_t j, int64_t p) {
+// M_k = max(M_k, |G_jk|) over the freshly cached columns (slots s0 .. s1 - 1 of the device store; j != k: a coordinate's own
+// column is the one whose slot the map names for it): the bound of k_cov_solve's certificates.  One launch per batch of columns.
+__global__ __launch_bounds__(256) void k_cov_colmax(double* __restrict__ colmax, const double* __restrict__ G, const int32_t* __restrict__ slot,
+                                                    int64_t s0, int64_t s1, int64_t p) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= p || k == j) return;
-    const double v = fabs(col[k]);
-    if (v > colmax[k] || v != v) colmax[k] = v;       // (a NaN entry poisons the bound: nothing is certified against it)
+    if (k >= p) return;
+    const int64_t own = slot[k];
+    double m = colmax[k];
+    bool poisoned = false;
+    for (int64_t s_ = s0; s_ < s1; ++s_) {
+        if (s_ == own) continue;
+        const double v = fabs(G[s_ * p + k]);
+        if (v > m) m = v;
+        if (v != v) poisoned = true;                  // (a NaN entry poisons the bound: nothing is certified against it)
+    }
+    colmax[k] = poisoned ? __builtin_nan("") : m;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -1260,11 +1288,8 @@ int32_t cs_update_colmax(cdh_handle h) {
     if (c.colmax_slots > c.dev_slots) c.colmax_slots = 0;          // the store was refilled from slot 0
     if (c.colmax_slots == c.dev_slots) return CDH_OK;
     if (c.colmax_slots == 0) HIPCHK(h, hipMemsetAsync(c.d_colmax, 0, sizeof(double) * (size_t)h->p, h->stream));
-    std::vector<int64_t> coord((size_t)c.dev_slots, -1);
-    for (int64_t k = 0; k < h->p; ++k) if (c.slot[(size_t)k] >= 0 && c.slot[(size_t)k] < c.dev_slots) coord[(size_t)c.slot[(size_t)k]] = k;
-    for (int64_t s_ = c.colmax_slots; s_ < c.dev_slots; ++s_)
-        hipLaunchKernelGGL(k_cov_colmax, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_colmax, c.d_G + s_ * h->p,
-                           coord[(size_t)s_], h->p);
+    hipLaunchKernelGGL(k_cov_colmax, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_colmax, c.d_G, c.d_slot,
+                       c.colmax_slots, c.dev_slots, h->p);
     HIPCHK(h, hipGetLastError());
     c.colmax_slots = c.dev_slots;
     return CDH_OK;
@@ -1304,9 +1329,8 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     if (!c.d_G || !c.d_scan || c.dev_slots != (int64_t)c.G.size() || (int64_t)c.moved.size() > h->p) return not_now();
     for (int64_t s_ = 0; s_ < h->x.nnz(); ++s_) if (c.slot[(size_t)h->x.coord(s_)] < 0) return not_now();
     if (h->x.nnz() > gc_max_support(h)) return not_now();
-    // One workgroup serves supports whose Gram block fits its LDS: beyond that every visit's update of the tracked gradients
-    // is a gather through one CU (measured at benchmark/cd_bench.jl's shape, 774 non-zeros: 0.38 s against 0.11 s for the
-    // pass-by-pass kernels, which spread that update over the chip) -- larger supports stay with those.
+    // The LDS of workgroup 0 holds the Gram block of ~170 tracked coordinates (ucap); longer visit lists run from the Gram table
+    // and with the helpers (see the header).
     const size_t shuffle_bytes = 0;              // (a shuffle's scratch overlays the tracked Gram block)
     int ucap = kCsUcapMax;
     {
