@@ -223,7 +223,7 @@ def cfg1_cpu_vs_gpu(device=0):
     shuffled = {"cpu_port_ms": t_cpu_sh * 1e3, "gpu_ms": t_gpu_sh * 1e3, "passes": f.last_stats["passes"], "cpu_passes": sts["passes"],
                 "visits": f.last_stats["visits"], "max_abs_beta_diff": float(np.max(np.abs(xs.dense() - xso.dense()))),
                 "same_support_order": bool(xs.nzval2ind.tolist() == xso.nzval2ind.tolist()),
-                "solve_kernel_us": f.onchip_last()["kernel_us"]}
+                "solve_kernel_us": f.onchip_last()["kernel_us"], "solve_kernel_steps": f.onchip_last()["steps"]}
     f.close()
     return {"workload": "lasso_n1000_p200_s10_lambda0.1_full_solve", "cpu_port_ms": t_cpu * 1e3, "cpu_cores": 1,
             "gpu_ms": t_gpu * 1e3, "gpu_ms_incl_upload_and_create": (t_gpu + t_up) * 1e3,

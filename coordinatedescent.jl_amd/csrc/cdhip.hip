@@ -141,6 +141,7 @@ struct GradCache {
             n_reconcile = 0;
     // the device-resident pass loop (cov_solve.hpp): its scratch, the pinned block it reads from and writes into, the bound's M_k
     bool cs_enabled = true;          // env CDH_COV_SOLVE (default 1)
+    bool cs_big = false;             // a visit list has outgrown the loop's LDS block on this handle: launches use the instantiation with the table and the helpers
     int cs_ucap_limit = 0;           // env CDH_CS_UCAP (tests): visit lists longer than this leave the LDS block
     int cs_helpers = 31;             // helper workgroups a launch that expects large visit lists brings (env CDH_CS_CREW; 0: none, table mode only)
     bool cs_shuffle_ok = true, cs_stalled = false;

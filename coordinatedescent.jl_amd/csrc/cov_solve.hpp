@@ -149,7 +149,7 @@ struct CsCrewView {      // what a helper touches (passed by value: a handful of
     CsCrew* crew; int64_t p; double* g; double* g_snap; const double* Gcols; const uint32_t* hold; const int32_t* vb;
     const uint8_t* setflag; const double* omega; const double* a; uint8_t* forced; const double* pendv; const int64_t* poff;
 };
-__device__ __attribute__((noinline)) void cs_crew_helper(const CovSolveCtl* ctl, const CsCrewView b) {
+__device__ __forceinline__ void cs_crew_helper(const CovSolveCtl* ctl, const CsCrewView b) {
     __shared__ double s_h[64], s_q[64];
     __shared__ int64_t s_off[64];
     __shared__ int s_pos[64];
@@ -252,8 +252,14 @@ struct CsTracked {
 };
 constexpr size_t kCsTrackedBytes = 3 * 8 + 7 * 8 + 4;      // per tracked coordinate
 
+// Two instantiations.  BIG = false is the loop as the common case needs it -- visit lists that fit the LDS block: no table, no helpers,
+// no call, no scratch (a kernel that asks for scratch makes the runtime map it for every wave slot of the chip on its first launch:
+// 14 ms measured, once per process; and the code of the large-list paths is a third of the kernel's 300 KB, all of it streamed through the
+// instruction cache once per pass otherwise).  A list that outgrows the block ends such a launch (kCsNeedBig); the host comes back
+// with BIG = true, and stays with it on that handle.
+template <bool BIG>
 __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovSolveBufs b, int ucap /* tracked coordinates whose Gram block fits LDS */) {
-    if (blockIdx.x != 0) { cs_crew_helper(ctl, CsCrewView{b.crew, b.p, b.g, b.g_snap, b.Gcols, b.hold, b.vb, b.setflag, b.omega, b.a, b.forced, b.pendv, b.poff}); return; }        // the crew (above): no barrier of workgroup 0 is theirs
+    if constexpr (BIG) if (blockIdx.x != 0) { cs_crew_helper(ctl, CsCrewView{b.crew, b.p, b.g, b.g_snap, b.Gcols, b.hold, b.vb, b.setflag, b.omega, b.a, b.forced, b.pendv, b.poff}); return; }        // the crew (above): no barrier of workgroup 0 is theirs
     using R = GramRec<4>;
     constexpr int B = R::B;
     constexpr int E = kCsE;
@@ -278,17 +284,21 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     double q = ctl->q;
     const double q_floor = ctl->q_floor;
     // 100 MHz ticks per phase (thread 0's view): list, scan, exact gradients, visits, re-check, accept, bookkeeping, dropzeros!
-    uint64_t tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (the phase clocks and the counters the host reads at the end live in LDS, kept by thread 0: a dozen 64-bit loop-carried values per
+    // thread otherwise, which the register allocator of the large-list instantiation pays for in scratch)
+    __shared__ unsigned long long s_tph[8];
+    __shared__ long long s_cnt[12];
+    enum { kFullPasses = 0, kVisits, kCovFull, kSettled, kFolds, kExact, kTablePasses, kTableRows, kForcedRounds, kCrewPasses, kCrewJobs };
     uint64_t tmark = __builtin_amdgcn_s_memrealtime();
     const uint64_t cyc0 = __builtin_amdgcn_s_memtime(), tick0 = tmark;
-    auto lap = [&](int ph) { const uint64_t now = __builtin_amdgcn_s_memrealtime(); tph[ph] += now - tmark; tmark = now; };
+    auto lap = [&](int ph) { const uint64_t now = __builtin_amdgcn_s_memrealtime(); if (tid == 0) s_tph[ph] += now - tmark; tmark = now; };
+    auto count = [&](int which, long long by) { if (tid == 0) s_cnt[which] += by; };
     int nnz = ctl->nnz, inject_count = ctl->inject_count;
     const int tcap = ctl->tcap, fold_limit = ctl->fold_limit, full_cap = ctl->full_cap;
     const int ucap_lists = ctl->ucap_limit > 0 ? min(ucap, ctl->ucap_limit) : ucap;      // the longest visit list that runs from the LDS block
     int ncid = ctl->ncid, tepoch = ctl->tepoch + 1;      // (gradients the table carried belong to the launch that carried them)
-    int64_t table_passes = 0, table_rows = 0, forced_rounds = 0, crew_passes = 0, crew_jobs = 0;
-    const int nhelp = (int)gridDim.x - 1;
-    const bool crew = nhelp > 0;
+    const int nhelp = BIG ? (int)gridDim.x - 1 : 0;
+    const bool crew = BIG && nhelp > 0;
     CsCrew* cw = b.crew;
     uint32_t njobs = 0, known_done = 0;
     bool crew_lost = false;
@@ -336,6 +346,8 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     if (crew) for (int64_t k = tid; k < p; k += kCsThreads) b.hold[k] = 0;
     for (int u = tid; u < ucap; u += kCsThreads) lt.iota[u] = u;
     if (tid == 0) {
+        for (int i = 0; i < 8; ++i) s_tph[i] = 0ull;
+        for (int i = 0; i < 12; ++i) s_cnt[i] = 0ll;
         s_nfail = 0;
         s_ctrl.lambda0 = lambda0; s_ctrl.n_total = n_total; s_ctrl.maxH = 0.0; s_ctrl.loss = loss; s_ctrl.has_omega = has_omega;
         s_ctrl.domain_error = 0; s_ctrl.pad = 0; s_ctrl.q_carry = q; s_ctrl.cert_abs = cert_abs;
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     }
     int pass_id = 1;             // gx_k is current iff gxp[k] == pass_id - 1: k was tracked in the pass just before
     int cnt_prev = -1;           // the tracked list G_UU in LDS was filled for (b.uprev[0 .. cnt_prev))
-    int64_t passes = 0, full_passes = 0, visits = 0, cov_visits = 0, cov_visits_full = 0, settled_total = 0, folds = 0, exact_rechecks = 0;
+    int64_t passes = 0, cov_visits = 0;      // (these two steer the loop; the other counters: s_cnt)
 
     auto stage_pending = [&]() {       // pend_m and the column offset of every coordinate moved since the fold
         for (int m = tid; m < nmoved; m += kCsThreads) {
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         for (int64_t k = tid; k < p; k += kCsThreads) b.g[k] = exact_g(k);
         for (int m = tid; m < nmoved; m += kCsThreads) { const int km = b.moved[m]; b.bfold[km] = b.beta[km]; b.inmoved[km] = 0; }
         __syncthreads();
-        nmoved = 0; TV0 = 0.0; folds += 1;
+        nmoved = 0; TV0 = 0.0; count(kFolds, 1);
     };
 
     for (;;) {
@@ -403,7 +415,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         if (cov_visits > cov_budget) { status = kCsRefresh; break; }
         if (sqrt_loss && q < q_floor) { status = kCsNeedQ; break; }      // r'r has run out of digits: the host sums it from r
         const bool full = conv;
-        if (full && nnz > full_cap && !crew) { status = kCsHostFull; break; }
+        if (full && nnz > full_cap && !crew) { status = BIG ? kCsHostFull : kCsNeedBig; break; }
         if (crew) {
             crew_wait(njobs);                                       // g is as current as the jobs posted so far make it
             if (full && nmoved > 0 && nnz + kCsTrackedMargin > ucap_lists) {
@@ -416,10 +428,10 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     if (tid == 0) cs_st_release(&cw->posted, njobs + 1);
                 }
-                njobs += 1; crew_jobs += 1;
+                njobs += 1; count(kCrewJobs, 1);
                 for (int m = tid; m < nmoved; m += kCsThreads) { const int km = b.moved[m]; b.bfold[km] = b.beta[km]; b.inmoved[km] = 0; }
                 crew_wait(njobs);
-                nmoved = 0; TV0 = 0.0; folds += 1; pass_id += 2; tepoch += 1;
+                nmoved = 0; TV0 = 0.0; count(kFolds, 1); pass_id += 2; tepoch += 1;
             }
             if (crew_lost) { status = kCsCrewLost; break; }
         }
@@ -546,8 +558,9 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         // kept current there, else g - sum_m pend_m G_m), their Gram block ----
         stage_pending();
         const bool in_lds = cnt <= ucap_lists;
-        const bool crewp = crew && !in_lds && full;      // a full pass over a visit list beyond the LDS-sized Gram block, helpers present: a crew pass
-        const bool table = !in_lds && !crewp;    // ... no helpers: the Gram TABLE in device memory (see k_cov_solve's header)
+        if (!BIG && !in_lds) { status = kCsNeedBig; rng = rng_before; break; }      // (the instantiation without the large-list paths)
+        const bool crewp = BIG && crew && !in_lds && full;      // a full pass over a visit list beyond the LDS-sized Gram block, helpers present: a crew pass
+        const bool table = BIG && !in_lds && !crewp;    // ... no helpers: the Gram TABLE in device memory (see k_cov_solve's header)
         if (table && cnt > tcap) { status = kCsOutgrown; rng = rng_before; break; }
         if (crewp && nmoved > 0) { status = kCsNeedFold; rng = rng_before; break; }     // (the helpers keep g itself current: nothing may be pending on it)
         const CsTracked T = in_lds ? lt : gt;
@@ -630,7 +643,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                         }
                 }
             }
-            table_rows += nnew; table_passes += 1;
+            count(kTableRows, nnew); count(kTablePasses, 1);
             ncid = ntot;
             __syncthreads();
             cnt_prev = -1;               // (the staging overwrote the LDS Gram block)
@@ -678,7 +691,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 }
             __syncthreads();
         }
-        if ((table || crewp) && cnt > 0) {
+        if constexpr (BIG) if ((table || crewp) && cnt > 0) {
             // Visit lists beyond the LDS block, two blocks in flight.
             // Table mode (active passes; full passes of a launch without helpers never get here): the update of the table's gradients
             // with a block's moves (64 rows of Gc, ~400 KB at 800 coordinates: the L1 of one CU moves that in ~4 us, as long as the block's
@@ -778,7 +791,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     if (tid == 0) cs_st_release(&cw->posted, njobs + 1);
                 }
-                njobs += 1; crew_jobs += 1;
+                njobs += 1; count(kCrewJobs, 1);
             };
             if (crewp) {
                 if (tid == 0) cw->bad = 0;                       // (every job is finished: nobody else touches it now)
@@ -860,7 +873,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             } else {
                 crew_wait(njobs);
                 if (tid == 0 && cs_ld_acquire(&cw->bad) != 0) s_bad = 1;
-                crew_passes += 1;
+                count(kCrewPasses, 1);
             }
             __syncthreads();
         }
@@ -935,11 +948,12 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 const double acc = b.g[kf] + part;
                 if (lane == 0 && !(fabs(acc) <= b.bsnap[f])) { s_bad = 1; b.forced[kf] = 1; }
             }
-            if (tid == 0) exact_rechecks += nfail;
+            count(kExact, nfail);
         }
         __syncthreads();
         if (tid == 0) s_nfail = 0;
         const bool crossed = s_bad != 0;
+        if (crossed) forced_dirty = true;      // (marks were set, by the re-check above or by the helpers: wiped after the next accepted full pass or at the exit)
         bool undo = crossed || s_nan != 0 || (nzero > 0 && (TV0 > 0.0 || tv_pass > 0.0));
         bool injected = false;
         if (full && cnt > 0 && inject_every > 0) { inject_count += 1; if (inject_count % inject_every == 0) { undo = true; injected = true; } }
@@ -952,12 +966,12 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     if (tid == 0) cs_st_release(&cw->posted, njobs + 1);
                 }
-                njobs += 1; crew_jobs += 1;
+                njobs += 1; count(kCrewJobs, 1);
             }
             // coordinates that crossed their threshold through the pass's own moves: the same pass again with those on the visit list
             // (visiting more than necessary is always right); after a few such rounds, or for anything else, the host walks it the careful way
             if (crossed && !injected && s_nan == 0 && !(nzero > 0 && (TV0 > 0.0 || tv_pass > 0.0)) && forced_rounds_here < kCsForcedRounds) {
-                forced_rounds_here += 1; forced_rounds += 1; forced_dirty = true;
+                forced_rounds_here += 1; count(kForcedRounds, 1); forced_dirty = true;
                 tepoch += 1;              // (the table's gradients have seen the undone moves)
                 __syncthreads();
                 continue;
@@ -1153,8 +1167,9 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 nnz = m;
             }
         }
-        passes += 1; visits += L; cov_visits += cnt; settled_total += L - cnt; lastH = s_ctrl.maxH;
-        if (full) { full_passes += 1; cov_visits_full += cnt; }
+        passes += 1; cov_visits += cnt; lastH = s_ctrl.maxH;
+        count(kVisits, L); count(kSettled, L - cnt);
+        if (full) { count(kFullPasses, 1); count(kCovFull, cnt); }
         prev_conv = conv;
         conv = lastH < optTol;
         if (prev_conv && conv) { status = kCsConverged; break; }
@@ -1170,23 +1185,16 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     if (forced_dirty) for (int64_t k = tid; k < p; k += kCsThreads) b.forced[k] = 0;
     for (int s = tid; s < nnz; s += kCsThreads) { const int k = b.s2i[s]; b.out_sup_idx[s] = k; b.out_sup_val[s] = b.beta[k]; }
     for (int m = tid; m < nmoved; m += kCsThreads) { const int km = b.moved[m]; b.out_moved_idx[m] = km; b.out_moved_val[m] = b.beta[km] - b.bfold[km]; }
-    {   // exact re-checks were counted per thread
-        __shared__ unsigned long long s_sum;
-        if (tid == 0) s_sum = 0ull;
-        __syncthreads();
-        if (exact_rechecks) atomicAdd(&s_sum, (unsigned long long)exact_rechecks);
-        __syncthreads();
-        exact_rechecks = (int64_t)s_sum;
-    }
     if (tid == 0) {
         ctl->rng = rng; ctl->q = q; ctl->nnz = nnz; ctl->prev_conv = prev_conv ? 1 : 0; ctl->conv = conv ? 1 : 0;
-        ctl->ncid = ncid; ctl->tepoch = tepoch; ctl->table_passes = table_passes; ctl->table_rows = table_rows; ctl->forced_rounds = forced_rounds; ctl->crew_passes = crew_passes; ctl->crew_jobs = crew_jobs;
+        ctl->ncid = ncid; ctl->tepoch = tepoch; ctl->table_passes = s_cnt[kTablePasses]; ctl->table_rows = s_cnt[kTableRows];
+        ctl->forced_rounds = s_cnt[kForcedRounds]; ctl->crew_passes = s_cnt[kCrewPasses]; ctl->crew_jobs = s_cnt[kCrewJobs];
         ctl->inject_count = inject_count; ctl->status = status; ctl->n_list = n_list; ctl->n_moved = nmoved;
-        ctl->domain_error = dom_any; ctl->passes = passes; ctl->full_passes = full_passes; ctl->visits = visits;
-        ctl->cov_visits = cov_visits; ctl->cov_visits_full = cov_visits_full; ctl->settled = settled_total; ctl->folds = folds; ctl->exact_rechecks = exact_rechecks;
+        ctl->domain_error = dom_any; ctl->passes = passes; ctl->full_passes = s_cnt[kFullPasses]; ctl->visits = s_cnt[kVisits];
+        ctl->cov_visits = cov_visits; ctl->cov_visits_full = s_cnt[kCovFull]; ctl->settled = s_cnt[kSettled]; ctl->folds = s_cnt[kFolds]; ctl->exact_rechecks = s_cnt[kExact];
         ctl->maxH = lastH;
         lap(7);
-        for (int i = 0; i < 8; ++i) ctl->ticks[i] = (int64_t)tph[i];
+        for (int i = 0; i < 8; ++i) ctl->ticks[i] = (int64_t)s_tph[i];
         ctl->cycles = (int64_t)(__builtin_amdgcn_s_memtime() - cyc0); ctl->ticks_total = (int64_t)(__builtin_amdgcn_s_memrealtime() - tick0);
     }
 }
@@ -1250,7 +1258,8 @@ int32_t cs_alloc(cdh_handle h) {
     b.vb = (int32_t*)take(4 * p); b.moved = (int32_t*)take(4 * p); b.holes = (int32_t*)take(4 * p); b.fills = (int32_t*)take(4 * p);
     b.gxp = (int32_t*)take(4 * p); b.upos = (int32_t*)take(4 * p); b.aidx = (int32_t*)take(4 * p); b.occ = (int32_t*)take(4 * p);
     b.setflag = (uint8_t*)take(p); b.inmoved = (uint8_t*)take(p); b.forced = (uint8_t*)take(p);
-    if (hipMemset(b.forced, 0, p) != hipSuccess) return fail(h, CDH_HIP_ERROR, "hipMemset (the device loop's marks)");
+    // (on the handle's own stream: the first operation on the NULL stream of a process creates its queue -- 10 ms measured)
+    HIPCHK(h, hipMemsetAsync(b.forced, 0, p, h->stream));
     c.d_colmax = (double*)take(8 * p);
     b.colmax = c.d_colmax;
     b.Gc = (double*)take(8 * tc * tc); b.gxc = (double*)take(8 * tc); b.cidk = (int64_t*)take(8 * tc); b.gxe = (int32_t*)take(4 * tc);
@@ -1274,7 +1283,8 @@ int32_t cs_alloc(cdh_handle h) {
     c.colmax_slots = 0;
     // dynamic LDS: the tracked coordinates' Gram block and, for shuffled sweeps, the shuffle's two p-sized arrays
     c.cs_lds_budget = kCsLdsBudget;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cov_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCsLdsBudget) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cov_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCsLdsBudget) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cov_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCsLdsBudget) != hipSuccess) {
         (void)hipGetLastError();
         c.cs_lds_budget = (size_t)36 * 1024;          // what the default 64 KB leave next to the kernel's static arrays
     }
@@ -1400,8 +1410,11 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     const unsigned lds = (unsigned)(8 * cs_tri_doubles((size_t)ucap) + (kCsTrackedBytes + 8) * (size_t)ucap + shuffle_bytes);
     if (o->randomize && 24 * ((size_t)h->p + 1) > (size_t)lds) return not_now();   // the shuffle's scratch overlays the dynamic LDS
     const int nh = ctl.tcap > 0 ? nhelp : 0;
+    // the instantiation with the large-list paths once a list has outgrown the LDS block on this handle (or is about to: helpers are coming)
+    const bool big = ctl.tcap > 0 && (c.cs_big || nh > 0 || h->x.nnz() + lds_margin / 2 > ucap_lists - lds_margin);
     if (nh > 0) HIPCHK(h, hipMemsetAsync(b.crew, 0, sizeof(CsCrew), h->stream));
-    hipLaunchKernelGGL(k_cov_solve, dim3(1 + nh), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
+    if (big) hipLaunchKernelGGL(k_cov_solve<true>, dim3(1 + nh), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
+    else hipLaunchKernelGGL(k_cov_solve<false>, dim3(1), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     c.n_cs_launches += 1;
@@ -1464,6 +1477,9 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     case kCsNeedQ: c.q_valid = false; CHK(gc_ensure_q(h)); *outcome = kCsAgain; return CDH_OK;
     case kCsNeedFold: gc_fold(h); *outcome = kCsAgain; return CDH_OK;
     case kCsCrewLost: return fail(h, CDH_HIP_ERROR, "the device-resident solve lost its helper workgroups (a wait ran into its 20 s bound)");
+    case kCsNeedBig:                                                // a visit list has outgrown the LDS block: the instantiation that knows what to do
+        if (ctl.tcap == 0) return CDH_OK;                           // (no room for its scratch in LDS: the host's passes)
+        c.cs_big = true; *outcome = kCsAgain; return CDH_OK;
     case kCsHostFull: return CDH_OK;                                // the next (full) pass runs the pass-by-pass way
     case kCsBusy:     // many inactive coordinates about to move: back off (1, 2, 4 ... 16 plain passes), as gc_pass_device does
         c.cooldown = c.backoff; c.backoff = std::min(16, 2 * c.backoff);

@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-enum { kCsConverged = 0, kCsMaxIter = 1, kCsNeedColumns = 2, kCsRollback = 3, kCsBusy = 4, kCsRefresh = 5, kCsOutgrown = 6, kCsNeedQ = 7, kCsNeedFold = 8, kCsHostFull = 9, kCsCrewLost = 10 };
+enum { kCsConverged = 0, kCsMaxIter = 1, kCsNeedColumns = 2, kCsRollback = 3, kCsBusy = 4, kCsRefresh = 5, kCsOutgrown = 6, kCsNeedQ = 7, kCsNeedFold = 8, kCsHostFull = 9, kCsCrewLost = 10, kCsNeedBig = 11 };
 
 struct CovSolveCtl {
     // in

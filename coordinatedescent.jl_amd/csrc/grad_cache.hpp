@@ -686,6 +686,7 @@ int32_t gc_pass_device(cdh_handle h, const int64_t* idx0, int64_t m, double* max
         // (tests: CDH_GC_INJECT_ROLLBACK=N declares every N-th device pass failed after the fact, so that the undo and the
         // windowed walk that takes over are exercised on every problem of the suite, not only where a certificate breaks)
         const bool injected = c.inject_rollback > 0 && (++c.inject_count % c.inject_rollback) == 0;
+        if ((int64_t)c.h_scan->bad_pos < m) c.forced_dirty = true;     // (marks were set: wiped when this function returns)
         if ((int64_t)c.h_scan->bad_pos < m || injected) {       // a skipped certificate did not survive the pass's own moves: undo
             hipLaunchKernelGGL(k_cov_restore, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, h->stream, c.d_g, h->beta, c.d_g_snap,
                                c.d_beta_snap, h->p);
