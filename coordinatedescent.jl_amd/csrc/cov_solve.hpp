@@ -922,9 +922,29 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 }
             }
             __syncthreads();
-            // g_k - sum_(pending) pend_m G_mk - sum_(visits before its turn) h_i G_ik: one listed coordinate per wave, its terms over the lanes
+            // g_k - sum_(pending) pend_m G_mk - sum_(visits before its turn) h_i G_ik.  Few listed coordinates: one per wave, its terms over the
+            // lanes (benchmark/cd_bench.jl's path: ~20 per pass with hundreds of terms each, 4 us apiece when one thread walked them).  Many
+            // (scaledLasso!'s sigma steps loosen the bound for thousands at once, with a few dozen terms each): one per THREAD, eight gathers in
+            // flight -- 0.04 us apiece with every thread busy against 0.28 us through the waves.
             const int nfail = s_nfail;
             const int lane = tid & 63, wave = tid >> 6;
+            if (nfail >= 2 * kCsThreads) {
+                for (int f = tid; f < nfail; f += kCsThreads) {
+                    const int64_t kf = b.holes[f];
+                    const int vf = b.fills[f];
+                    double acc = exact_g(kf);
+                    int i = 0;
+                    for (; i + 8 <= vf; i += 8) {
+                        double gv[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) gv[t] = b.Gcols[b.voff[i + t] + kf];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) acc = fma(-b.hs[i + t], gv[t], acc);
+                    }
+                    for (; i < vf; ++i) acc = fma(-b.hs[i], b.Gcols[b.voff[i] + kf], acc);
+                    if (!(fabs(acc) <= b.bsnap[f])) { s_bad = 1; b.forced[kf] = 1; }
+                }
+            } else
             for (int f = wave; f < nfail; f += kCsWaves) {
                 const int64_t kf = b.holes[f];
                 const int vf = b.fills[f];
