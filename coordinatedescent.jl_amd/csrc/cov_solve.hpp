@@ -811,6 +811,8 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 if (more && part == 1) stage_ids(par ^ 1, j0 + B);            // the next block's ids, for its gather during this block's visits
                 // (A) this block's gradients: as the rows / the helpers left them, then the moves of the block before, in visit order
                 double tv_[B / kCsWaves];
+                double v0 = 0.0;                                   // (table mode: the rows of the block before last are in gxc since the barrier; on its way with the tile)
+                if (!crewp && tid < B) v0 = b.gxc[s_cid2[par][tid]];
                 if (pend_n > 0) {
 #pragma unroll
                     for (int r = 0; r < B / kCsWaves; ++r) {
@@ -818,7 +820,10 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                         tv_[r] = crewp ? b.Gcols[s_off2[(par ^ 1) * B + i] + s_k2[par * B + lane_t]] : b.Gc[(size_t)s_mu2[par ^ 1][i] * tcap + s_cid2[par][lane_t]];
                     }
                 }
-                if (crewp) crew_wait(njobs > 0 ? njobs - 1 : 0);      // everything but the job just posted is finished (that one leaves this block's coordinates alone)
+                if (crewp) {
+                    crew_wait(njobs > 0 ? njobs - 1 : 0);          // everything but the job just posted is finished (that one leaves this block's coordinates alone)
+                    if (tid < B) v0 = b.g[s_k2[par * B + tid]];
+                }
                 const double q_blk = s_ctrl.q_carry;
                 if (pend_n > 0) {
 #pragma unroll
@@ -826,11 +831,10 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     __syncthreads();
                 }
                 if (tid < B) {
-                    double* src = crewp ? b.g + s_k2[par * B + tid] : b.gxc + s_cid2[par][tid];
-                    double v = *src;
+                    double v = v0;
                     for (int i = 0; i < pend_n; ++i) v = fma(-hprev[i], s_tile[i * B + tid], v);
                     rec[R::OFF_C + tid] = tid < nb ? v : 0.0;
-                    if (crewp && pend_n > 0 && tid < nb) *src = v;
+                    if (crewp && pend_n > 0 && tid < nb) b.g[s_k2[par * B + tid]] = v;
                 }
                 if (tid == 0) { rec[R::OFF_Q] = q_blk; s_task = 0; }
                 __syncthreads();
