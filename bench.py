@@ -281,6 +281,44 @@ def cfg3_path(device=0, n=2_000_000, p=5000, nlam=100):
         f.close()
 
 
+def ref_shape_path(device=0):
+    """The reference's OWN benchmark shape (benchmark/cd_bench.jl:10-14: n = 3000, p = 5000, s = 100, noise 6) as a warm-started
+    60-lambda LassoPath (src/lasso.jl:229-260; omega = _stdX!, optTol 1e-7, ordered sweeps) from 0.95 to 0.03 lambda_max, where
+    the support reaches several hundred non-zeros -- timed for context, never part of `value`, and CHECKED against the CPU port
+    of the oracle on the same data (beta at the last lambda, tolerance 1e-10).  The first run on the handle fetches the Gram
+    columns of the coordinates that enter; `seconds` is the better of the two runs that follow."""
+    import numpy as np
+    import coordinatedescent_jl_amd as cd
+    import oracle as O
+    rng = np.random.default_rng(123)
+    n, p, s = 3000, 5000, 100
+    X = np.asfortranarray(rng.standard_normal((n, p)))
+    Y = X[:, :s] @ (rng.standard_normal(s) * (1.0 + rng.random(s))) + 6.0 * rng.standard_normal(n)
+    lmax = float(np.max(np.abs(X.T @ Y) / np.sqrt((X * X).mean(axis=0)))) / n
+    lams = lmax * np.exp(np.linspace(np.log(0.95), np.log(0.03), 60))
+    o = dict(maxIter=2000, optTol=1e-7, randomize=False)
+    f = cd.CDLeastSquaresLoss(Y, X, device=device)
+    try:
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            path = cd.LassoPath(f, None, lams, cd.CDOptions(**o))
+            f._L.cdh_synchronize(f._h)
+            times.append(time.perf_counter() - t0)
+        beta = path.betapath[-1].dense()
+        t0 = time.perf_counter()
+        _, bo = O.LassoPath(X, Y, lams, O.CDOptions(**o))
+        t_cpu = time.perf_counter() - t0
+        ls = f.device_loop_stats()
+        return {"workload": "lasso_path_60_lambdas_n3000_p5000_f64_warm_started (benchmark/cd_bench.jl's shape)", "seconds": min(times[1:]),
+                "seconds_first_run_on_the_handle": times[0], "cpu_port_seconds": t_cpu, "cpu_cores": 1, "nnz_last": int(path.betapath[-1].nnz),
+                "max_abs_beta_diff_last_lambda": float(np.max(np.abs(beta - bo[-1]))), "tolerance": 1e-10,
+                "device_loop": {"launches": ls["launches"], "passes": ls["passes"], "table_passes": ls["table"]["passes"],
+                                "helper_passes": ls["crew"]["passes"], "helper_jobs": ls["crew"]["jobs"]}}
+    finally:
+        f.close()
+
+
 def isolated_exchange_probe(cp, device, what="p2p", timeout_s=150):
     """One child process per rank (same GPU, fresh rendezvous port) runs coordinatedescent.jl_amd/p2p_probe.py in mode
     `what` ("p2p": the direct exchange; "rccl": the communicator's bring-up and probe sums).  Returns (ok on every rank,
@@ -392,7 +430,7 @@ def main():
     ap.add_argument("--no-exchange-trial", action="store_true",
                     help="with --exchange auto: skip the second region (same as --exchange rccl)")
     ap.add_argument("--no-cfg1", action="store_true", help="skip the cfg1 (n=1000, p=200) CPU-vs-GPU solve timing")
-    ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg3 (100-lambda path, n=2e6, p=5000) timing")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg3 (100-lambda path, n=2e6, p=5000) timing and the 60-lambda path at the reference's benchmark shape")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 --pmc child runs (the committed figure is used)")
     a = ap.parse_args()
@@ -747,6 +785,11 @@ def main():
             res["cfg3_path"] = cfg3_path(device)
         except Exception as e:
             res["cfg3_path"] = {"error": str(e)[:200]}
+    if cp.rank == 0 and cp.world == 1 and default_workload and not a.no_cfg3 and not a.no_cpu_baseline:
+        try:
+            res["ref_shape_path"] = ref_shape_path(device)
+        except Exception as e:
+            res["ref_shape_path"] = {"error": str(e)[:200]}
     if cp.rank == 0:
         print(json.dumps(res), flush=True)
     cp.shutdown()
