@@ -292,3 +292,28 @@ def test_device_loop_helpers_undo_a_full_pass_and_restore_the_gradient(inject, m
         assert cs["rollbacks"] > 0, cs
     np.testing.assert_allclose(f.r, fo.r, rtol=0, atol=1e-8)
     f.close()
+
+
+def test_device_loop_helpers_leave_no_trace_of_their_number():
+    """The helpers keep g current coordinate by coordinate, each for a fixed slice, the jobs in order: what a solve returns
+    must not depend on how many there are, bit for bit -- nor, beyond rounding, on whether there are any.  The reference's
+    own benchmark shape (benchmark/cd_bench.jl:10-14), 24 lambdas down to ~290 non-zeros."""
+    rng = np.random.default_rng(123)
+    n, p, s = 3000, 5000, 100
+    X = np.asfortranarray(rng.standard_normal((n, p)))
+    Y = X[:, :s] @ (rng.standard_normal(s) * (1.0 + rng.random(s))) + 6.0 * rng.standard_normal(n)
+    lmax = float(np.max(np.abs(X.T @ Y) / np.sqrt((X * X).mean(axis=0)))) / n
+    lams = lmax * np.exp(np.linspace(np.log(0.5), np.log(0.05), 24))
+    o = dict(maxIter=2000, optTol=1e-7, randomize=False)
+    got = {}
+    for helpers in (None, 5, 0):
+        f = cd.CDLeastSquaresLoss(Y, X)
+        f.set_device_loop(True, helpers=helpers)
+        path = cd.LassoPath(f, None, lams, cd.CDOptions(**o))
+        got[helpers] = np.stack([b_.dense() for b_ in path.betapath])
+        ls = f.device_loop_stats()
+        assert (ls["crew"]["passes"] > 0) == (helpers != 0) and ls["table"]["passes"] > 0, (helpers, ls)
+        assert path.betapath[-1].nnz > 250
+        f.close()
+    assert np.array_equal(got[None], got[5])
+    np.testing.assert_allclose(got[0], got[None], rtol=0, atol=1e-11)
