@@ -132,9 +132,11 @@ __device__ __forceinline__ int cs_block_sum(int v, int* s_w) {
 // host's device pass) -- is p x 64 gathers: microseconds for thirty workgroups, ~1 ms for one.  So a launch that expects such
 // lists brings helpers: workgroups 1 .. of the same grid.  Workgroup 0 runs the state machine as before and POSTS one job per
 // block (the block's moves: h, column offsets, visit indices, r'r after each); the helpers take the jobs in order, each for
-// its slice of the coordinates, and report per helper how many they have finished.  Workgroup 0 never waits for the job it has
-// just posted: the 64 gradients the next block needs it brings up to date itself (a 64 x 64 tile of Gram entries, the same
-// sums in the same order) and tells the helpers to leave those coordinates alone for that job (hold[k] = the job's tag).
+// its slice of the coordinates, and report per helper how many they have finished.  Workgroup 0 does not wait for them inside a
+// pass at all: its own visits run from the Gram table (gxc: the exact gradients of the coordinates it visits, kept current by the
+// table's rows), the helpers' g is read again only when the next pass scans, and their verdict on the skipped coordinates when
+// the pass is over.  (A first version had workgroup 0 read the visited coordinates' gradients from g itself, one job behind:
+// 19 us per block of visits against 12 -- an agent-scope acquire per block empties the XCD's L2 under the visits.)
 // Memory model: job data and g are ordinary device memory; a post is release (agent scope) after the data, a take is acquire;
 // a helper's report is release after its stores, workgroup 0's wait acquire.  Every spin is bounded by the wall clock (100 MHz
 // counter): a helper that hears nothing for kCsCrewPatience leaves, workgroup 0 gives up a wait after the same time and the
@@ -146,7 +148,7 @@ __device__ __forceinline__ uint32_t cs_ld_relaxed(const uint32_t* p) { return __
 __device__ __forceinline__ void cs_st_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct CsCrewView {      // what a helper touches (passed by value: a handful of registers)
-    CsCrew* crew; int64_t p; double* g; double* g_snap; const double* Gcols; const uint32_t* hold; const int32_t* vb;
+    CsCrew* crew; int64_t p; double* g; double* g_snap; const double* Gcols; const int32_t* vb;
     const uint8_t* setflag; const double* omega; const double* a; uint8_t* forced; const double* pendv; const int64_t* poff;
 };
 __device__ __forceinline__ void cs_crew_helper(const CovSolveCtl* ctl, const CsCrewView b) {
@@ -176,7 +178,7 @@ __device__ __forceinline__ void cs_crew_helper(const CovSolveCtl* ctl, const CsC
         const int go = s_go;
         if (!go) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const CsCrewJob* job = &cw->ring[seen & 1];
+        const CsCrewJob* job = &cw->ring[seen % (uint32_t)kCsCrewRing];
         const int kind = job->kind;
         if (kind == kCrewSnapshot) {
             for (int64_t k = (int64_t)hid * kCsThreads + tid; k < p; k += (int64_t)nh * kCsThreads) b.g_snap[k] = b.g[k];
@@ -199,12 +201,10 @@ __device__ __forceinline__ void cs_crew_helper(const CovSolveCtl* ctl, const CsC
             }
         } else {
             const int nmove = job->nmove, j0 = job->j0, nb = job->nb, chk = job->chk, last_block = job->last_block;
-            const uint32_t tag = job->hold_tag;
             const double q_start = job->q_start;
             if (tid < 64) { s_h[tid] = job->h[tid]; s_q[tid] = job->q[tid]; s_off[tid] = job->off[tid]; s_pos[tid] = job->pos[tid]; }
             __syncthreads();
             for (int64_t k = (int64_t)hid * kCsThreads + tid; k < p; k += (int64_t)nh * kCsThreads) {
-                if (b.hold[k] == tag) continue;                   // workgroup 0 has brought this one up to date itself
                 const int t = b.vb[k];                            // (a skipped coordinate: the visits before its turn)
                 bool need = chk != 0 && b.setflag[k] != 0 && t >= j0 && (last_block != 0 || t < j0 + nb);
                 if (nmove == 0 && !need) continue;
@@ -259,7 +259,7 @@ constexpr size_t kCsTrackedBytes = 3 * 8 + 7 * 8 + 4;      // per tracked coordi
 // with BIG = true, and stays with it on that handle.
 template <bool BIG>
 __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovSolveBufs b, int ucap /* tracked coordinates whose Gram block fits LDS */) {
-    if constexpr (BIG) if (blockIdx.x != 0) { cs_crew_helper(ctl, CsCrewView{b.crew, b.p, b.g, b.g_snap, b.Gcols, b.hold, b.vb, b.setflag, b.omega, b.a, b.forced, b.pendv, b.poff}); return; }        // the crew (above): no barrier of workgroup 0 is theirs
+    if constexpr (BIG) if (blockIdx.x != 0) { cs_crew_helper(ctl, CsCrewView{b.crew, b.p, b.g, b.g_snap, b.Gcols, b.vb, b.setflag, b.omega, b.a, b.forced, b.pendv, b.poff}); return; }        // the crew (above): no barrier of workgroup 0 is theirs
     using R = GramRec<4>;
     constexpr int B = R::B;
     constexpr int E = kCsE;
@@ -343,7 +343,6 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     const CsTracked gt{b.uk, b.voff, b.iota, b.ubeta, b.uom, b.ugx, b.hs, b.newval, b.qs, b.tv, b.touched};   // ... and the global one
 
     for (int64_t k = tid; k < p; k += kCsThreads) { b.i2s[k] = 0; b.bfold[k] = b.beta[k]; b.inmoved[k] = 0; b.gxp[k] = -1; b.iota[k] = k; }
-    if (crew) for (int64_t k = tid; k < p; k += kCsThreads) b.hold[k] = 0;
     for (int u = tid; u < ucap; u += kCsThreads) lt.iota[u] = u;
     if (tid == 0) {
         for (int i = 0; i < 8; ++i) s_tph[i] = 0ull;
@@ -423,8 +422,8 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 // into g first -- p x moves gathers, the helpers' work
                 stage_pending();
                 if (tid < 64) {
-                    CsCrewJob* job = &cw->ring[njobs & 1];
-                    if (tid == 0) { job->kind = kCrewFold; job->nmove = nmoved; job->hold_tag = njobs + 1; }
+                    CsCrewJob* job = &cw->ring[njobs % (uint32_t)kCsCrewRing];
+                    if (tid == 0) { job->kind = kCrewFold; job->nmove = nmoved; }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     if (tid == 0) cs_st_release(&cw->posted, njobs + 1);
                 }
@@ -559,8 +558,8 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         stage_pending();
         const bool in_lds = cnt <= ucap_lists;
         if (!BIG && !in_lds) { status = kCsNeedBig; rng = rng_before; break; }      // (the instantiation without the large-list paths)
-        const bool crewp = BIG && crew && !in_lds && full;      // a full pass over a visit list beyond the LDS-sized Gram block, helpers present: a crew pass
-        const bool table = BIG && !in_lds && !crewp;    // ... no helpers: the Gram TABLE in device memory (see k_cov_solve's header)
+        const bool table = BIG && !in_lds;               // a visit list beyond the LDS-sized Gram block: the Gram TABLE in device memory (see k_cov_solve's header)
+        const bool crewp = table && crew && full;        // ... and, in a full pass with helpers present, a job per block of visits for them ("a crew pass")
         if (table && cnt > tcap) { status = kCsOutgrown; rng = rng_before; break; }
         if (crewp && nmoved > 0) { status = kCsNeedFold; rng = rng_before; break; }     // (the helpers keep g itself current: nothing may be pending on it)
         const CsTracked T = in_lds ? lt : gt;
@@ -599,7 +598,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             if (table) {                 // the table carries the exact gradient of every coordinate it holds through all the moves of table-mode passes
                 const int c = b.ucid[u];
                 if (b.gxe[c] != tepoch) { b.gxc[c] = (gp == pass_id - 1) ? gxk : exact_g(k); b.gxe[c] = tepoch; }
-            } else if (!crewp) {
+            } else {
                 T.gx[u] = (gp == pass_id - 1) ? gxk : exact_g(k);
             }
             if (kprev != k) s_same = 0;
@@ -691,7 +690,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 }
             __syncthreads();
         }
-        if constexpr (BIG) if ((table || crewp) && cnt > 0) {
+        if constexpr (BIG) if (table && cnt > 0) {
             // Visit lists beyond the LDS block, two blocks in flight.
             // Table mode (active passes; full passes of a launch without helpers never get here): the update of the table's gradients
             // with a block's moves (64 rows of Gc, ~400 KB at 800 coordinates: the L1 of one CU moves that in ~4 us, as long as the block's
@@ -708,8 +707,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             static_assert(R::N <= 2688, "the second block record");
             double* s_tile = s_dynamic + 2688;                                       // [64 moves][64 coordinates] of the block about to be visited
             int64_t* s_off2 = reinterpret_cast<int64_t*>(s_dynamic + 6784);           // crew: [2][B] column offsets of a block's moves
-            int64_t* s_k2 = s_off2 + 2 * B;                                          //       [2][B] coordinates of a block
-            double* s_q2 = reinterpret_cast<double*>(s_k2 + 2 * B);                  //       [2][B] r'r after each move
+            double* s_q2 = reinterpret_cast<double*>(s_off2 + 2 * B);                //       [2][B] r'r after each move
             int* s_pos2 = reinterpret_cast<int*>(s_q2 + 2 * B);                      //       [2][B] visit index of each move
             int64_t* s_v2 = reinterpret_cast<int64_t*>(s_pos2 + 2 * B);              //       [2][B] column offsets of a block's coordinates
             const int lane_t = tid & 63, part = tid >> 6;
@@ -717,15 +715,15 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             constexpr int NGV = (B * B + (kCsThreads - 64) - 1) / (kCsThreads - 64);
             double gv[NGV];
             auto stage_ids = [&](int which, int jb) {            // the coordinates (crew) / table ids of block jb into LDS, by one wave's lanes
-                if (crewp) { s_k2[which * B + lane_t] = T.k[min(jb + lane_t, cnt - 1)]; s_v2[which * B + lane_t] = T.voff[min(jb + lane_t, cnt - 1)]; }
-                else s_cid2[which][lane_t] = b.ucid[min(jb + lane_t, cnt - 1)];
+                s_cid2[which][lane_t] = b.ucid[min(jb + lane_t, cnt - 1)];
+                if (crewp) s_v2[which * B + lane_t] = T.voff[min(jb + lane_t, cnt - 1)];       // (the jobs name a move by its column)
             };
             auto gather_block = [&](int which) {
                 if (tid < 64) return;
 #pragma unroll
                 for (int t = 0; t < NGV; ++t) {
                     const int e = min(tid - 64 + (kCsThreads - 64) * t, B * B - 1), j = e & (B - 1), sI = e / B;
-                    gv[t] = crewp ? b.Gcols[s_v2[which * B + j] + s_k2[which * B + sI]] : b.Gc[(size_t)s_cid2[which][j] * tcap + s_cid2[which][sI]];
+                    gv[t] = b.Gc[(size_t)s_cid2[which][j] * tcap + s_cid2[which][sI]];
                 }
             };
             auto store_block = [&](double* rec, int nbn) {
@@ -775,27 +773,28 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     *reinterpret_cast<double4*>(b.gxc + c0) = acc;       // (ids beyond ncid up to the next multiple of four: scratch nobody reads)
                 }
             };
-            // crew: one job; wave 0 writes it (the slot's previous job -- two posts ago -- is finished: every caller has waited for njobs - 1)
-            auto crew_post = [&](int kind, int par, int nmv, int j0, int nb, int chk, int last, int hold_j0, double q_start) {
-                if (tid < 64) {
-                    CsCrewJob* job = &cw->ring[njobs & 1];
+            // crew: one job, written by wave 3 (wave 0 goes straight on to the next block).  The ring holds a pass's worth of jobs, so the slot
+            // written is free unless a pass has more than kCsCrewRing blocks: then, and only then, the helpers are waited for inside a pass
+            auto crew_post = [&](int kind, int par, int nmv, int j0, int nb, int chk, int last, double q_start) {
+                if (njobs >= (uint32_t)kCsCrewRing) crew_wait(njobs - (uint32_t)kCsCrewRing + 1u);
+                if (part == 3) {
+                    CsCrewJob* job = &cw->ring[njobs % (uint32_t)kCsCrewRing];
                     if (kind == kCrewUpdate) {
-                        job->h[tid] = tid < nmv ? s_h2[par][tid] : 0.0; job->q[tid] = s_q2[par * B + tid];
-                        job->off[tid] = s_off2[par * B + tid]; job->pos[tid] = s_pos2[par * B + tid];
-                        if (hold_j0 >= 0 && hold_j0 + tid < cnt) b.hold[T.k[hold_j0 + tid]] = njobs + 1;
+                        job->h[lane_t] = lane_t < nmv ? s_h2[par][lane_t] : 0.0; job->q[lane_t] = s_q2[par * B + lane_t];
+                        job->off[lane_t] = s_off2[par * B + lane_t]; job->pos[lane_t] = s_pos2[par * B + lane_t];
                     }
-                    if (tid == 0) {
+                    if (lane_t == 0) {
                         job->kind = kind; job->nmove = nmv; job->j0 = j0; job->nb = nb; job->chk = chk; job->last_block = last; job->cnt = cnt;
-                        job->hold_tag = njobs + 1; job->q_start = q_start;
+                        job->q_start = q_start;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    if (tid == 0) cs_st_release(&cw->posted, njobs + 1);
+                    if (lane_t == 0) cs_st_release(&cw->posted, njobs + 1);
                 }
                 njobs += 1; count(kCrewJobs, 1);
             };
             if (crewp) {
                 if (tid == 0) cw->bad = 0;                       // (every job is finished: nobody else touches it now)
-                crew_post(kCrewSnapshot, 0, 0, 0, 0, 0, 0, -1, 0.0);          // g as the pass finds it, should the pass have to be undone
+                crew_post(kCrewSnapshot, 0, 0, 0, 0, 0, 0, 0.0);              // g as the pass finds it, should the pass have to be undone
             }
             if (part == 1) stage_ids(0, 0);
             __syncthreads();
@@ -812,17 +811,13 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 // (A) this block's gradients: as the rows / the helpers left them, then the moves of the block before, in visit order
                 double tv_[B / kCsWaves];
                 double v0 = 0.0;                                   // (table mode: the rows of the block before last are in gxc since the barrier; on its way with the tile)
-                if (!crewp && tid < B) v0 = b.gxc[s_cid2[par][tid]];
+                if (tid < B) v0 = b.gxc[s_cid2[par][tid]];
                 if (pend_n > 0) {
 #pragma unroll
                     for (int r = 0; r < B / kCsWaves; ++r) {
                         const int i = min(part + kCsWaves * r, pend_n - 1);
-                        tv_[r] = crewp ? b.Gcols[s_off2[(par ^ 1) * B + i] + s_k2[par * B + lane_t]] : b.Gc[(size_t)s_mu2[par ^ 1][i] * tcap + s_cid2[par][lane_t]];
+                        tv_[r] = b.Gc[(size_t)s_mu2[par ^ 1][i] * tcap + s_cid2[par][lane_t]];
                     }
-                }
-                if (crewp) {
-                    crew_wait(njobs > 0 ? njobs - 1 : 0);          // everything but the job just posted is finished (that one leaves this block's coordinates alone)
-                    if (tid < B) v0 = b.g[s_k2[par * B + tid]];
                 }
                 const double q_blk = s_ctrl.q_carry;
                 if (pend_n > 0) {
@@ -834,7 +829,6 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     double v = v0;
                     for (int i = 0; i < pend_n; ++i) v = fma(-hprev[i], s_tile[i * B + tid], v);
                     rec[R::OFF_C + tid] = tid < nb ? v : 0.0;
-                    if (crewp && pend_n > 0 && tid < nb) b.g[s_k2[par * B + tid]] = v;
                 }
                 if (tid == 0) { rec[R::OFF_Q] = q_blk; s_task = 0; }
                 __syncthreads();
@@ -850,8 +844,8 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     if (nz) {
                         const int at = __popcll(mask & ((1ull << tid) - 1ull));
                         s_h2[par][at] = hv;
+                        s_mu2[par][at] = s_cid2[par][tid];
                         if (crewp) { s_off2[par * B + at] = s_v2[par * B + tid]; s_pos2[par * B + at] = j0 + tid; s_q2[par * B + at] = sqrt_loss ? T.qs[j0 + tid] : 0.0; }
-                        else s_mu2[par][at] = s_cid2[par][tid];
                     }
                     if (__ballot(hv != hv)) { if (tid == 0) s_nan = 1; }
                     double run = (hv == hv) ? fabs(hv) : 0.0;
@@ -863,18 +857,17 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                     const double last = __shfl(run, 63, 64);
                     if (tid == 0) s_tvrun = base + last;
                 }
-                if (table && pend_n > 0) rows_update(hprev, s_mu2[par ^ 1], pend_n);
+                if (pend_n > 0) rows_update(hprev, s_mu2[par ^ 1], pend_n);
                 __syncthreads();
                 pend_n = s_nmove;
                 // (C) crew: the block's moves go to the helpers (a block without moves is posted too: its job re-checks, and every job names
                 // the coordinates of the block after it as workgroup 0's own)
-                if (crewp) crew_post(kCrewUpdate, par, pend_n, j0, nb, 1, more ? 0 : 1, more ? j0 + B : -1, q_blk);
+                if (crewp) crew_post(kCrewUpdate, par, pend_n, j0, nb, 1, more ? 0 : 1, q_blk);
             }
-            if (table) {
-                if (tid == 0) s_task = 0;
-                __syncthreads();
-                if (pend_n > 0) rows_update(s_h2[(nch - 1) & 1], s_mu2[(nch - 1) & 1], pend_n);
-            } else {
+            if (tid == 0) s_task = 0;
+            __syncthreads();
+            if (pend_n > 0) rows_update(s_h2[(nch - 1) & 1], s_mu2[(nch - 1) & 1], pend_n);
+            if (crewp) {                  // the helpers' verdict on the skipped coordinates (their g is needed again only when the next pass scans)
                 crew_wait(njobs);
                 if (tid == 0 && cs_ld_acquire(&cw->bad) != 0) s_bad = 1;
                 count(kCrewPasses, 1);
@@ -985,8 +978,8 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             rng = rng_before;
             if (crewp && cnt > 0) {       // ... once g is what it was (the helpers had moved it along)
                 if (tid < 64) {
-                    CsCrewJob* job = &cw->ring[njobs & 1];
-                    if (tid == 0) { job->kind = kCrewRestore; job->nmove = 0; job->hold_tag = njobs + 1; }
+                    CsCrewJob* job = &cw->ring[njobs % (uint32_t)kCsCrewRing];
+                    if (tid == 0) { job->kind = kCrewRestore; job->nmove = 0; }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     if (tid == 0) cs_st_release(&cw->posted, njobs + 1);
                 }
@@ -1021,7 +1014,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             int at[1];
             const int tot = cs_rank<1>(neu, at, s_w);
             if (neu[0]) { b.moved[nmoved + at[0]] = (int32_t)k; b.inmoved[k] = 1; }
-            if (in && !crewp) { b.gxp[k] = pass_id; b.gx[k] = table ? b.gxc[b.ucid[u]] : T.gx[u]; }
+            if (in) { b.gxp[k] = pass_id; b.gx[k] = table ? b.gxc[b.ucid[u]] : T.gx[u]; }
             if (in) { b.beta[k] = T.beta[u]; if (crewp) b.bfold[k] = T.beta[u]; }
             nmoved += tot;
         }
@@ -1256,7 +1249,7 @@ int32_t cs_alloc(cdh_handle h) {
     const size_t tc = (size_t)kCsTableCap;
     const size_t dev_bytes = 11 * cs_align(8 * p) + 5 * cs_align(8 * p) + 12 * cs_align(4 * p) + 3 * cs_align(p) + cs_align(8 * p) /* colmax */ +
                              cs_align(8 * tc * tc) + 2 * cs_align(8 * tc) + cs_align(4 * tc) + 3 * cs_align(4 * p) /* the Gram table */ +
-                             cs_align(sizeof(CsCrew)) + cs_align(8 * p) + cs_align(4 * p) /* the crew: jobs, g's snapshot, the hold tags */;
+                             cs_align(sizeof(CsCrew)) + cs_align(8 * p) /* the crew: jobs, g's snapshot */;
     const size_t pin_bytes = cs_align(sizeof(CovSolveCtl)) + 4 * cs_align(4 * p) + 2 * cs_align(8 * p);
     void* dev_view = nullptr;
     bool fits = hipMalloc((void**)&c.cs_dev, dev_bytes) == hipSuccess && hipHostMalloc((void**)&c.cs_pin, pin_bytes) == hipSuccess &&
@@ -1289,7 +1282,7 @@ int32_t cs_alloc(cdh_handle h) {
     b.Gc = (double*)take(8 * tc * tc); b.gxc = (double*)take(8 * tc); b.cidk = (int64_t*)take(8 * tc); b.gxe = (int32_t*)take(4 * tc);
     b.cidof = (int32_t*)take(4 * p); b.ucid = (int32_t*)take(4 * p); b.newc = (int32_t*)take(4 * p);
     c.cs_ncid = 0; c.cs_table_reset = true;
-    b.crew = (CsCrew*)take(sizeof(CsCrew)); b.g_snap = (double*)take(8 * p); b.hold = (uint32_t*)take(4 * p);
+    b.crew = (CsCrew*)take(sizeof(CsCrew)); b.g_snap = (double*)take(8 * p);
     // the pinned block, as the host and as the device address it
     size_t o = cs_align(sizeof(CovSolveCtl));
     auto pin = [&](size_t bytes) { const size_t at = o; o += cs_align(bytes); return at; };
@@ -1436,7 +1429,7 @@ int32_t cov_solve(cdh_handle h, const cdh_options* o, cdh::VisitScheduler& sched
     const int nh = ctl.tcap > 0 ? nhelp : 0;
     // the instantiation with the large-list paths once a list has outgrown the LDS block on this handle (or is about to: helpers are coming)
     const bool big = ctl.tcap > 0 && (c.cs_big || nh > 0 || h->x.nnz() + lds_margin / 2 > ucap_lists - lds_margin);
-    if (nh > 0) HIPCHK(h, hipMemsetAsync(b.crew, 0, sizeof(CsCrew), h->stream));
+    if (nh > 0) HIPCHK(h, hipMemsetAsync(b.crew, 0, offsetof(CsCrew, ring), h->stream));      // the counters and flags (the jobs are written before they are posted)
     if (big) hipLaunchKernelGGL(k_cov_solve<true>, dim3(1 + nh), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
     else hipLaunchKernelGGL(k_cov_solve<false>, dim3(1), dim3(kCsThreads), lds, h->stream, reinterpret_cast<CovSolveCtl*>(c.cs_pin_dev), b, ucap);
     HIPCHK(h, hipGetLastError());

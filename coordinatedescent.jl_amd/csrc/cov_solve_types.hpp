@@ -33,10 +33,11 @@ struct CovSolveCtl {
 // The crew: helper workgroups of the same launch that keep g = X'r current for ALL p coordinates while workgroup 0 visits
 // (cov_solve.hpp, "crew passes").  Workgroup 0 posts one job per block of visits; the helpers take them in order.
 constexpr int kCsCrewMax = 64;
+constexpr int kCsCrewRing = 16;        // jobs in flight: a full pass over 1024 visits posts without ever waiting
 enum { kCrewUpdate = 1, kCrewSnapshot = 2, kCrewRestore = 3, kCrewFold = 4 };
 struct CsCrewJob {
     int32_t kind, nmove, j0, nb, chk, last_block, cnt, pad;
-    uint32_t hold_tag, pad1;
+    uint32_t pad1, pad2;
     double q_start;
     double h[64], q[64];
     int64_t off[64];
@@ -45,7 +46,7 @@ struct CsCrewJob {
 struct CsCrew {
     uint32_t posted, exit_flag, bad, lost;
     uint32_t done[kCsCrewMax];
-    CsCrewJob ring[2];
+    CsCrewJob ring[kCsCrewRing];
 };
 
 struct CovSolveBufs {
@@ -63,7 +64,6 @@ struct CovSolveBufs {
     // crew passes
     CsCrew* crew;
     double* g_snap;
-    uint32_t* hold;
     const int32_t* in_sup;                   // the support in slot order (pinned host memory, read once)
     int32_t *out_sup_idx, *out_moved_idx, *out_list;   // pinned host memory, written once at the end
     double *out_sup_val, *out_moved_val;
