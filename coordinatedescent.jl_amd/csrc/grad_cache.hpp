@@ -109,8 +109,11 @@ int32_t gc_dev_reserve(cdh_handle h, int64_t have) {
         c.d_forced = c.d_setflag + p; c.forced_dirty = false;
         c.g_dev_ok = false; c.a_dev_ok = false;
     }
-    if (have > c.dev_slots_cap) {   // grow the store (64 columns at a time, at most kGcMaxBytes), keeping what is there
-        const int64_t cap = std::min<int64_t>((have + 63) / 64 * 64 + 64, (int64_t)(kGcMaxBytes / sizeof(double)) / std::max<int64_t>(p, 1));
+    if (have > c.dev_slots_cap) {   // grow the store (at least 64 columns more, doubling once it holds 128: a path that ends at 800 columns
+                                    // reallocates 5 times, not 14 -- each is a hipMalloc, a copy and a hipFree, milliseconds apiece on a
+                                    // fresh handle; at most kGcMaxBytes), keeping what is there
+        const int64_t most = (int64_t)(kGcMaxBytes / sizeof(double)) / std::max<int64_t>(p, 1);
+        const int64_t cap = std::min<int64_t>(std::max<int64_t>((have + 63) / 64 * 64 + 64, c.dev_slots_cap >= 128 ? 2 * c.dev_slots_cap : 0), most);
         if (cap < have) { c.cov = false; return CDH_OK; }   // does not fit (the same on every rank): residual form
         double* bigger = nullptr;
         bool fits = hipMalloc((void**)&bigger, sizeof(double) * (size_t)cap * (size_t)p) == hipSuccess;
