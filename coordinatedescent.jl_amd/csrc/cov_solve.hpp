@@ -301,8 +301,8 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     const bool crew = BIG && nhelp > 0;
     CsCrew* cw = b.crew;
     uint32_t njobs = 0, known_done = 0;
-    bool crew_lost = false;
     __shared__ uint32_t s_known;
+    __shared__ int s_crew_lost;          // a wait for the helpers ran into its bound (kept in LDS: set in one place, read after barriers)
     // every helper has finished `target` jobs (called by all threads; the spin is bounded by the wall clock)
     auto crew_wait = [&](uint32_t target) {
         if (target <= known_done) return;
@@ -318,11 +318,10 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o < v ? o : v; }
-            if (tid == 0) s_known = v;
+            if (tid == 0) { s_known = v; if (v < target) s_crew_lost = 1; }
         }
         __syncthreads();
         known_done = s_known;
-        if (known_done < target) crew_lost = true;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
     };
@@ -345,6 +344,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     for (int64_t k = tid; k < p; k += kCsThreads) { b.i2s[k] = 0; b.bfold[k] = b.beta[k]; b.inmoved[k] = 0; b.gxp[k] = -1; b.iota[k] = k; }
     for (int u = tid; u < ucap; u += kCsThreads) lt.iota[u] = u;
     if (tid == 0) {
+        s_crew_lost = 0;
         for (int i = 0; i < 8; ++i) s_tph[i] = 0ull;
         for (int i = 0; i < 12; ++i) s_cnt[i] = 0ll;
         s_nfail = 0;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 crew_wait(njobs);
                 nmoved = 0; TV0 = 0.0; count(kFolds, 1); pass_id += 2; tepoch += 1;
             }
-            if (crew_lost) { status = kCsCrewLost; break; }
+            if (s_crew_lost) { status = kCsCrewLost; break; }
         }
         const uint64_t rng_before = rng;
         const int L = full ? (int)p : nnz;
@@ -713,25 +713,27 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             const int lane_t = tid & 63, part = tid >> 6;
             // (the next block's Gram entries are fetched by waves 1-3 only: loads return in order, and wave 0's visits start with loads of their own)
             constexpr int NGV = (B * B + (kCsThreads - 64) - 1) / (kCsThreads - 64);
-            double gv[NGV];
+            static_assert(NGV % 2 == 0, "two rounds");
             auto stage_ids = [&](int which, int jb) {            // the coordinates (crew) / table ids of block jb into LDS, by one wave's lanes
                 s_cid2[which][lane_t] = b.ucid[min(jb + lane_t, cnt - 1)];
                 if (crewp) s_v2[which * B + lane_t] = T.voff[min(jb + lane_t, cnt - 1)];       // (the jobs name a move by its column)
             };
-            auto gather_block = [&](int which) {
+            // the next block's Gram entries, two rounds of eleven gathers per thread of waves 1-3, each round stored as it lands
+            auto fetch_block = [&](int which, double* rec, int nbn) {
                 if (tid < 64) return;
 #pragma unroll
-                for (int t = 0; t < NGV; ++t) {
-                    const int e = min(tid - 64 + (kCsThreads - 64) * t, B * B - 1), j = e & (B - 1), sI = e / B;
-                    gv[t] = b.Gc[(size_t)s_cid2[which][j] * tcap + s_cid2[which][sI]];
-                }
-            };
-            auto store_block = [&](double* rec, int nbn) {
-                if (tid < 64) return;
+                for (int half = 0; half < 2; ++half) {
+                    double gv[NGV / 2];
 #pragma unroll
-                for (int t = 0; t < NGV; ++t) {
-                    const int e = tid - 64 + (kCsThreads - 64) * t, sI = e / B, j = e & (B - 1);
-                    if (e < B * B && sI <= j && j < nbn) rec[R::g(sI, j)] = gv[t];
+                    for (int t = 0; t < NGV / 2; ++t) {
+                        const int e = min(tid - 64 + (kCsThreads - 64) * (half * (NGV / 2) + t), B * B - 1), j = e & (B - 1), sI = e / B;
+                        gv[t] = b.Gc[(size_t)s_cid2[which][j] * tcap + s_cid2[which][sI]];
+                    }
+#pragma unroll
+                    for (int t = 0; t < NGV / 2; ++t) {
+                        const int e = tid - 64 + (kCsThreads - 64) * (half * (NGV / 2) + t), sI = e / B, j = e & (B - 1);
+                        if (e < B * B && sI <= j && j < nbn) rec[R::g(sI, j)] = gv[t];
+                    }
                 }
             };
             auto rows_update = [&](const double* hb, const int* mub, int nmv) {   // table mode: gxc -= sum_i h_i Gc[mu_i][.], moves in visit order
@@ -798,8 +800,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
             }
             if (part == 1) stage_ids(0, 0);
             __syncthreads();
-            gather_block(0);
-            store_block(recb(0), min(B, cnt));
+            fetch_block(0, recb(0), min(B, cnt));
             __syncthreads();
             int pend_n = 0;                                       // moves of the block before, not yet in gxc / in this block's gradients
             for (int ch = 0; ch < nch; ++ch) {
@@ -833,7 +834,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
                 if (tid == 0) { rec[R::OFF_Q] = q_blk; s_task = 0; }
                 __syncthreads();
                 // (B) wave 0 visits; table mode: the others bring gxc up to date with the block before; the next block's Gram entries are on the way
-                if (more) { gather_block(par ^ 1); store_block(recb(par ^ 1), min(B, cnt - j0 - B)); }
+                if (more) fetch_block(par ^ 1, recb(par ^ 1), min(B, cnt - j0 - B));
                 if (tid < 64) {
                     gram_scalar_body<4>(rec, nb, 0, &s_ctrl, T.beta, T.om, T.iota, T.hs, T.nv, T.tch, j0, T.qs, tid);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
         if (s_ctrl.domain_error) dom_any = 1;
 
         // ---- the settled positions, re-checked with the bound as it stood at their turn; exactly where the bound fails ----
-        if (crew_lost) { status = kCsCrewLost; break; }
+        if (crew && s_crew_lost) { status = kCsCrewLost; break; }
         if (full && cnt < L && (tv_pass > 0.0 || TV0 > 0.0) && !crewp) {      // (a crew pass: the helpers have re-checked on the way, with g itself)
             const int cm1 = cnt > 0 ? cnt - 1 : 0;
             for (int64_t k0 = 0; k0 < p; k0 += kCsThreads * E) {
@@ -1196,7 +1197,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cov_solve(CovSolveCtl* ctl, CovS
     __syncthreads();
     if (crew) {                           // the helpers finish what is posted, then leave
         crew_wait(njobs);
-        if (crew_lost) status = kCsCrewLost;
+        if (s_crew_lost) status = kCsCrewLost;
         if (tid == 0) cs_st_release(&cw->exit_flag, 1u);
     }
     if (forced_dirty) for (int64_t k = tid; k < p; k += kCsThreads) b.forced[k] = 0;
