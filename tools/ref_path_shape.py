@@ -2,7 +2,7 @@
 """LassoPath (src/lasso.jl:229-260; omega = _stdX!, optTol 1e-7, ordered) at the reference's own benchmark shape
 (benchmark/cd_bench.jl: n = 3000, p = 5000, s = 100, noise 6): 60 lambdas from 0.95 to 0.03 lambda_max (774 non-zeros at the
 end), the GPU path with the gradient cache in its default mode / forced / off, and with the device-resident pass loop off
-(CDH_COV_SOLVE=0 in the environment).  Prints one line per mode; the CPU port's time with CPU=1."""
+(CDH_COV_SOLVE=0 in the environment).  Prints one line per mode; the CPU port's time with CPU=1; shuffled sweeps with RANDOMIZE=1."""
 import os
 import sys
 import time
@@ -18,7 +18,8 @@ X = np.asfortranarray(rng.standard_normal((n, p)))
 Y = X[:, :s] @ (rng.standard_normal(s) * (1.0 + rng.random(s))) + 6.0 * rng.standard_normal(n)
 lmax = float(np.max(np.abs(X.T @ Y) / np.sqrt((X * X).mean(axis=0)))) / n
 lams = lmax * np.exp(np.linspace(np.log(0.95), np.log(0.03), 60))
-o = dict(maxIter=2000, optTol=1e-7, randomize=False)
+# RANDOMIZE=1: shuffled sweeps, the reference's default order (CDOptions.randomize = true, src/utils.jl:18), seeded on both sides
+o = dict(maxIter=2000, optTol=1e-7, randomize=bool(int(os.environ.get("RANDOMIZE", "0"))), seed=11)
 ref = None
 for mode in (1, 3, 0):
     f = cd.CDLeastSquaresLoss(Y, X)
