@@ -62,7 +62,7 @@ __device__ __forceinline__ uint64_t small_rng_next(uint64_t& state) {
 // off the buckets, resolve the pred chains (they strictly decrease) by pointer doubling in ceil(log2 L) rounds, and gather.
 // Same permutation as the loop, bit for bit (tests: the oracle's visit orders; tests/test_host_cpp.py's scheduler).
 // NT threads (one wave, or one workgroup) call it together; `sync` is their barrier.  All arrays in LDS: draw[L] (in: j_i for
-// i < L - 1), cnt[L], off[L + 1], bucket[L], par[L], out[L] (the permutation); s_x: NT / 64 ints.
+// i < L - 1), cnt[L], off[L + 1], bucket[L], par[L], out[L] (the permutation); s_x: max(NT / 64, 3) ints (a workgroup's).
 template <int NT, typename Sync>
 __device__ __forceinline__ int pfy_thread_prefix(int v, int tid, int* s_x, Sync sync) {     // exclusive prefix of v over the threads
     int inc = v;
@@ -104,12 +104,27 @@ __device__ __forceinline__ void parallel_fisher_yates(int tid, int L, int32_t* d
         out[i] = P;
         par[i] = pr >= 0 ? pr : i;
     }
+    if constexpr (NT > 64) { if (tid == 0) { s_x[0] = 0; s_x[1] = 0; s_x[2] = 0; } }
     sync();
-    int32_t *cur = par, *nxt = cnt;                  // pointer doubling, double-buffered (cnt is free by now)
-    for (int span = 1; span < L; span <<= 1) {
-        for (int i = tid; i < L; i += NT) nxt[i] = cur[cur[i]];
-        sync();
+    // pointer doubling, double-buffered (cnt is free by now), until nothing moves: the chains are a few links long (steps that
+    // share a target), so two or three of the ceil(log2 L) rounds do.  One wave: a ballot says so; a workgroup: three rotating
+    // flags in s_x (set in round r, read after its barrier, cleared two rounds later -- no barrier of their own)
+    int32_t *cur = par, *nxt = cnt;
+    for (int span = 1, r = 0; span < L; span <<= 1, ++r) {
+        bool moved = false;
+        for (int i = tid; i < L; i += NT) { const int c0 = cur[i], c1 = cur[c0]; nxt[i] = c1; moved |= c1 != c0; }
+        bool any;
+        if constexpr (NT > 64) {
+            if (moved) s_x[r % 3] = 1;
+            if (tid == 0) s_x[(r + 1) % 3] = 0;
+            sync();
+            any = s_x[r % 3] != 0;
+        } else {
+            any = __ballot(moved) != 0ull;
+            sync();
+        }
         int32_t* t = cur; cur = nxt; nxt = t;
+        if (!any) break;
     }
     for (int i = tid; i < L; i += NT) { const int P = out[i]; out[i] = P >= 0 ? cur[P] : draw[i]; }
     sync();
