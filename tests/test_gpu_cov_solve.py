@@ -172,8 +172,8 @@ def test_sqrt_lasso_near_noiseless_keeps_its_residual_norm(loop):
     f.close()
 
 
-@pytest.mark.parametrize("kind,rand", [("ls", False), ("ls", True), ("sqrt", False), ("wl1", True)],
-                         ids=["ls-ordered", "ls-random", "sqrt-ordered", "wl1-random"])
+@pytest.mark.parametrize("kind,rand", [("ls", False), ("ls", True), ("sqrt", False), ("wl1", True), ("wls", False)],
+                         ids=["ls-ordered", "ls-random", "sqrt-ordered", "wl1-random", "wls-ordered"])
 def test_device_loop_table_mode_on_large_supports(kind, rand):
     """Visit lists beyond the LDS-sized Gram block (~150 non-zeros; benchmark/cd_bench.jl's path ends at 774).  Active passes:
     the loop reads X_j'X_k from its Gram table in device memory and carries the exact gradient of every coordinate the table
@@ -184,12 +184,13 @@ def test_device_loop_table_mode_on_large_supports(kind, rand):
     workgroup, with the loop off."""
     rng, X, Y = _problem(97, 1600, 1400, 300, noise=2.0)
     om = (rng.random(1400) + 0.5) if kind == "wl1" else None
+    w = rng.random(1600) + 0.5                                   # (observation weights of the weighted-LS variant)
     if kind == "sqrt":
         lams = list(np.exp(np.linspace(np.log(3.2), np.log(1.6), 14))) + [2.4]
     else:
         lams = list(np.exp(np.linspace(np.log(0.5), np.log(0.1), 14))) + [0.3]
     o = dict(maxIter=5000, optTol=1e-9, randomize=rand, seed=41)
-    fo = O.CDSqrtLassoLoss(Y, X) if kind == "sqrt" else O.CDLeastSquaresLoss(Y, X)
+    fo = _losses(kind, Y, X, w)[1]
     xo, want = O.SparseIterate(1400), []
     for lam in lams:
         st = O.coordinateDescent_(xo, fo, O.ProxL1(lam, om), O.CDOptions(**o))
@@ -199,7 +200,7 @@ def test_device_loop_table_mode_on_large_supports(kind, rand):
     assert max(sizes) > 300 and min(sizes) < 250, sizes
     got = {}
     for mode in ("helpers", "one workgroup", "host loop"):
-        f = cd.CDSqrtLassoLoss(Y, X) if kind == "sqrt" else cd.CDLeastSquaresLoss(Y, X)
+        f = _losses(kind, Y, X, w)[0]
         f.set_gradient_cache(3)
         f.set_onchip_solve(False)
         if mode == "helpers":
