@@ -282,9 +282,10 @@ def test_random_call_sequences_on_one_fp32_handle(seed, monkeypatch):
         monkeypatch.setenv("CDH_GC_REFRESH", str(int(rng.integers(20, 400))))
     if rng.integers(0, 3) == 0:
         monkeypatch.setenv("CDH_GC_INJECT_ROLLBACK", str(int(rng.integers(1, 4))))
+    monkeypatch.setenv("CDH_CS_UCAP", ["0", "0", "5", "10"][int(rng.integers(0, 4))])     # (the device loop's table and helpers on small supports)
     X = np.asfortranarray((rng.standard_normal((n, p)) * rng.uniform(0.5, 2.0, size=p)).astype(np.float32))
     Y = (X[:, :s].astype(np.float64) @ rng.standard_normal(s) + rng.uniform(0.5, 2.0) * rng.standard_normal(n)).astype(np.float32)
-    log = [f"fp32 seed={seed} n={n} p={p}"]
+    log = [f"fp32 seed={seed} n={n} p={p} ucap={os.environ.get('CDH_CS_UCAP')}"]
     f = cd.CDLeastSquaresLoss(Y, X)
     assert f.r.dtype == np.float32
     f.set_gradient_cache(int(rng.choice([0, 1, 2, 3, 3])))
@@ -327,7 +328,9 @@ def test_random_call_sequences_on_one_fp32_handle(seed, monkeypatch):
             cd.initialize_(f, x)
             log.append(f"columns {j0}..{j0 + nc - 1} replaced")
         _switch_paths(rng, f, log)
-    for k, v in dict(f.cache_stats(), onchip_solves=f.onchip_stats()["solves"]).items():
+    ls = f.device_loop_stats()
+    for k, v in dict(f.cache_stats(), onchip_solves=f.onchip_stats()["solves"], loop_table_passes=ls["table"]["passes"],
+                     loop_helper_passes=ls["crew"]["passes"]).items():
         REACHED["fp32_" + k] = REACHED.get("fp32_" + k, 0) + int(v)
     f.close()
 
