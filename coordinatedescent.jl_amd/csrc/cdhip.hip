@@ -128,6 +128,7 @@ struct GradCache {
     int64_t n_dev_passes = 0;
     int inject_rollback = 0, inject_count = 0;   // env CDH_GC_INJECT_ROLLBACK (tests)
     int64_t dev_slots_cap = 0, dev_slots = 0;   // columns the device store can hold / holds
+    std::vector<double*> d_G_retired;           // stores outgrown on the way (freed with the handle)
     int64_t cov_since_ref = 0;      // covariance-form visits since g was last taken from X itself
     int64_t refresh_after = 0;      // ... after which it is (kGcCovRefresh; env CDH_GC_REFRESH for tests)
     std::vector<double> g_new;      // g as a covariance-form chunk left it, until the chunk is accepted
@@ -1152,6 +1153,7 @@ void free_all(cdh_handle h) {
     if (h->gc.d_cross_part) (void)hipFree(h->gc.d_cross_part);
     if (h->gc.d_g) (void)hipFree(h->gc.d_g);
     if (h->gc.d_G) (void)hipFree(h->gc.d_G);
+    for (double* q : h->gc.d_G_retired) (void)hipFree(q);
     if (h->gc.d_slot) (void)hipFree(h->gc.d_slot);
     if (h->gc.h_g_pin) (void)hipHostFree(h->gc.h_g_pin);
     if (h->small.d_G) (void)hipFree(h->small.d_G);

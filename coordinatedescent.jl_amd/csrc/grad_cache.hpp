@@ -123,7 +123,10 @@ int32_t gc_dev_reserve(cdh_handle h, int64_t have) {
         if (c.d_G && c.dev_slots > 0)
             HIPCHK(h, hipMemcpyAsync(bigger, c.d_G, sizeof(double) * (size_t)c.dev_slots * (size_t)p, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (c.d_G) (void)hipFree(c.d_G);
+        // (the store it replaces is released with the handle: hipFree synchronises the device and, after large allocations have gone,
+        // can take tens of milliseconds -- seen as one 66 ms solve in the first path of a process that had freed 80 GB; the stores a
+        // handle outgrows add up to less than the one it ends with)
+        if (c.d_G) c.d_G_retired.push_back(c.d_G);
         c.d_G = bigger; c.dev_slots_cap = cap;
     }
     return CDH_OK;
